@@ -1,0 +1,322 @@
+// C ABI of libcrt_hip.so (declarations and contracts: include/crt_hip.h).
+#include <hip/hip_runtime_api.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/crt_hip.h"
+#include "crt_render.hpp"
+#include "crt_scene.hpp"
+
+// 2 x 64x64x4 float32 LTC tables, embedded from data/ltc_tables.f32 (crt_ltc_blob.cpp).
+extern "C" const unsigned char crt_ltc_tables_blob[];
+extern "C" const unsigned char crt_ltc_tables_blob_end[];
+
+struct crt_ctx {
+    int device = 0;
+    char err[512] = {0};
+    float* ltc_dev = nullptr;
+    crt::DevScene* scene_dev = nullptr;
+    crt::DevScene scene_host;
+    bool has_scene = false;
+    uint32_t* rng_dev = nullptr;      // 6 planes of npix words
+    uint32_t* rng_init_d = nullptr;   // plane 5 (d) as seeded, for draw counting
+    uint32_t* counters_dev = nullptr; // 2 planes of npix words: shade points, expansions
+    uint32_t rng_nx = 0, rng_ny = 0;
+};
+
+namespace {
+
+int fail(crt_ctx* ctx, int code, const char* fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) return fail(ctx, CRT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));    \
+    } while (0)
+
+int bind(crt_ctx* ctx) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return CRT_OK;
+}
+
+int check_settings(crt_ctx* ctx, const crt_settings* st) {
+    if (!st) return fail(ctx, CRT_ERR_INVALID, "settings is NULL");
+    if (st->nx == 0 || st->ny == 0) return fail(ctx, CRT_ERR_INVALID, "nx and ny must be positive");
+    if ((uint64_t)st->nx * st->ny > 0x7fffffffull) return fail(ctx, CRT_ERR_INVALID, "image too large");
+    if (st->gl_iter > CRT_MAX_GL_ITER)
+        return fail(ctx, CRT_ERR_UNSUPPORTED, "gl_iter %u exceeds CRT_MAX_GL_ITER (%u)", st->gl_iter, CRT_MAX_GL_ITER);
+    if (st->gl_iter > 0 && st->ind_rays == 0)
+        return fail(ctx, CRT_ERR_INVALID, "ind_rays must be positive when gl_iter > 0");
+    if (!ctx->has_scene) return fail(ctx, CRT_ERR_NO_SCENE, "no scene uploaded");
+    if (!ctx->rng_dev || ctx->rng_nx != st->nx || ctx->rng_ny != st->ny)
+        return fail(ctx, CRT_ERR_NO_RNG, "RNG states missing or sized for %ux%u, not %ux%u", ctx->rng_nx, ctx->rng_ny,
+                    st->nx, st->ny);
+    return CRT_OK;
+}
+
+crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
+    crt::RenderArgs a;
+    memset(&a, 0, sizeof a);
+    a.scene = ctx->scene_dev;
+    a.ltc = ctx->ltc_dev;
+    a.rng = ctx->rng_dev;
+    a.counters = ctx->counters_dev;
+    a.out = out;
+    a.nx = st->nx;
+    a.ny = st->ny;
+    a.aa_iter = st->aa_iter;
+    a.ref_iter = st->ref_iter;
+    a.gl_iter = st->gl_iter;
+    a.ind_rays = st->ind_rays;
+    a.tiles_x = (st->nx + 7u) / 8u;
+    a.tiles_y = (st->ny + 7u) / 8u;
+    a.world = 1;
+    return a;
+}
+
+} // namespace
+
+extern "C" {
+
+int crt_create(crt_ctx** out, int device) {
+    if (!out) return CRT_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CRT_ERR_HIP;
+    crt_ctx* ctx = new (std::nothrow) crt_ctx();
+    if (!ctx) return CRT_ERR_INVALID;
+    ctx->device = device;
+    const size_t ltc_bytes = (size_t)(crt_ltc_tables_blob_end - crt_ltc_tables_blob);
+    if (ltc_bytes != 2u * 64u * 64u * 4u * sizeof(float) || hipSetDevice(device) != hipSuccess ||
+        hipMalloc((void**)&ctx->ltc_dev, ltc_bytes) != hipSuccess ||
+        hipMemcpy(ctx->ltc_dev, crt_ltc_tables_blob, ltc_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void**)&ctx->scene_dev, sizeof(crt::DevScene)) != hipSuccess) {
+        crt_destroy(ctx);
+        return CRT_ERR_HIP;
+    }
+    *out = ctx;
+    return CRT_OK;
+}
+
+void crt_destroy(crt_ctx* ctx) {
+    if (!ctx) return;
+    if (hipSetDevice(ctx->device) == hipSuccess) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(ctx->ltc_dev);
+        (void)hipFree(ctx->scene_dev);
+        (void)hipFree(ctx->rng_dev);
+        (void)hipFree(ctx->rng_init_d);
+        (void)hipFree(ctx->counters_dev);
+    }
+    delete ctx;
+}
+
+const char* crt_last_error(const crt_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int crt_scene_upload(crt_ctx* ctx, const crt_scene_desc* scene) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!scene) return fail(ctx, CRT_ERR_INVALID, "scene is NULL");
+    int rc = crt::flatten_scene(scene, &ctx->scene_host, nullptr, ctx->err, sizeof ctx->err);
+    if (rc != CRT_OK) return rc;
+    if ((rc = bind(ctx)) != CRT_OK) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize()); // no render may still be reading the old scene
+    HIP_TRY(ctx, hipMemcpy(ctx->scene_dev, &ctx->scene_host, sizeof(crt::DevScene), hipMemcpyHostToDevice));
+    ctx->has_scene = true;
+    return CRT_OK;
+}
+
+int crt_rng_init(crt_ctx* ctx, uint32_t nx, uint32_t ny, uint64_t seed, void* stream) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (nx == 0 || ny == 0 || (uint64_t)nx * ny > 0x7fffffffull) return fail(ctx, CRT_ERR_INVALID, "bad image size");
+    int rc = bind(ctx);
+    if (rc != CRT_OK) return rc;
+    const size_t npix = (size_t)nx * ny;
+    if (ctx->rng_nx != nx || ctx->rng_ny != ny || !ctx->rng_dev) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        (void)hipFree(ctx->rng_dev);
+        (void)hipFree(ctx->rng_init_d);
+        (void)hipFree(ctx->counters_dev);
+        ctx->rng_dev = ctx->rng_init_d = ctx->counters_dev = nullptr;
+        ctx->rng_nx = ctx->rng_ny = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rng_dev, npix * 6 * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rng_init_d, npix * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->counters_dev, npix * 2 * sizeof(uint32_t)));
+        ctx->rng_nx = nx;
+        ctx->rng_ny = ny;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    crt::launch_random_init((uint32_t)npix, seed, ctx->rng_dev, s);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->rng_init_d, ctx->rng_dev + 5 * npix, npix * sizeof(uint32_t),
+                                hipMemcpyDeviceToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters_dev, 0, npix * 2 * sizeof(uint32_t), s));
+    return CRT_OK;
+}
+
+int crt_rng_export(crt_ctx* ctx, uint32_t* host_state6) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!host_state6) return fail(ctx, CRT_ERR_INVALID, "host_state6 is NULL");
+    if (!ctx->rng_dev) return fail(ctx, CRT_ERR_NO_RNG, "no RNG states");
+    int rc = bind(ctx);
+    if (rc != CRT_OK) return rc;
+    const size_t npix = (size_t)ctx->rng_nx * ctx->rng_ny;
+    std::vector<uint32_t> planes(npix * 6);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(planes.data(), ctx->rng_dev, npix * 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < npix; ++p)
+        for (int k = 0; k < 6; ++k) host_state6[p * 6 + k] = planes[(size_t)k * npix + p];
+    return CRT_OK;
+}
+
+int crt_render(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void* stream) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!fb_dev) return fail(ctx, CRT_ERR_INVALID, "fb_dev is NULL");
+    int rc = check_settings(ctx, st);
+    if (rc != CRT_OK) return rc;
+    if ((rc = bind(ctx)) != CRT_OK) return rc;
+    crt::RenderArgs a = base_args(ctx, st, fb_dev);
+    a.mode = crt::MODE_FULL;
+    crt::launch_render(a, a.tiles_x * a.tiles_y, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return CRT_OK;
+}
+
+int crt_render_partial(crt_ctx* ctx, const crt_settings* st, uint32_t tileIndex, float* fb_dev, void* stream) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!fb_dev) return fail(ctx, CRT_ERR_INVALID, "fb_dev is NULL");
+    int rc = check_settings(ctx, st);
+    if (rc != CRT_OK) return rc;
+    if (st->tx == 0 || st->ty == 0 || st->blocksPerDraw == 0)
+        return fail(ctx, CRT_ERR_INVALID, "tx, ty and blocksPerDraw must be positive");
+    if ((uint64_t)st->tx * st->ty > 1024u) return fail(ctx, CRT_ERR_INVALID, "tx*ty exceeds 1024 threads per block");
+    if ((rc = bind(ctx)) != CRT_OK) return rc;
+    // window arithmetic of the progressive loop (main.cu:719-727,752-754)
+    const uint32_t blocksX = st->nx / st->tx + 1, blocksY = st->ny / st->ty + 1;
+    const uint32_t bx = st->blocksPerDraw < blocksX ? st->blocksPerDraw : blocksX;
+    uint32_t by = st->blocksPerDraw / blocksX + 1;
+    if (by < 1) by = 1;
+    if (by > blocksY) by = blocksY;
+    crt::RenderArgs a = base_args(ctx, st, fb_dev);
+    a.mode = crt::MODE_PARTIAL;
+    a.tx = st->tx;
+    a.ty = st->ty;
+    a.blocks_x = blocksX;
+    a.blocks_y = blocksY;
+    a.win_bx = bx;
+    a.win_by = by;
+    a.start_bx = tileIndex % blocksX;
+    a.start_by = (tileIndex / blocksX) < blocksY ? (tileIndex / blocksX) : blocksY;
+    const uint64_t lanes = (uint64_t)bx * by * st->tx * st->ty;
+    crt::launch_render(a, (uint32_t)((lanes + 63u) / 64u), (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return CRT_OK;
+}
+
+uint32_t crt_shard_tiles(uint32_t nx, uint32_t ny, uint32_t rank, uint32_t world) {
+    if (world == 0 || rank >= world) return 0;
+    const uint32_t tiles = ((nx + 7u) / 8u) * ((ny + 7u) / 8u);
+    return tiles / world + (rank < tiles % world ? 1u : 0u);
+}
+
+uint32_t crt_shard_tiles_max(uint32_t nx, uint32_t ny, uint32_t world) {
+    if (world == 0) return 0;
+    const uint32_t tiles = ((nx + 7u) / 8u) * ((ny + 7u) / 8u);
+    return (tiles + world - 1u) / world;
+}
+
+int crt_render_shard(crt_ctx* ctx, const crt_settings* st, uint32_t rank, uint32_t world, float* compact_dev,
+                     void* stream) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!compact_dev) return fail(ctx, CRT_ERR_INVALID, "compact_dev is NULL");
+    if (world == 0 || rank >= world) return fail(ctx, CRT_ERR_INVALID, "rank %u out of world %u", rank, world);
+    int rc = check_settings(ctx, st);
+    if (rc != CRT_OK) return rc;
+    if ((rc = bind(ctx)) != CRT_OK) return rc;
+    crt::RenderArgs a = base_args(ctx, st, compact_dev);
+    a.mode = crt::MODE_SHARD;
+    a.rank = rank;
+    a.world = world;
+    // every rank launches tiles_max waves so that the padded tail is written as zeros
+    crt::launch_render(a, crt_shard_tiles_max(st->nx, st->ny, world), (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return CRT_OK;
+}
+
+int crt_scatter_shards(crt_ctx* ctx, uint32_t nx, uint32_t ny, uint32_t world, const float* gathered_dev,
+                       float* fb_dev, void* stream) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!gathered_dev || !fb_dev || world == 0 || nx == 0 || ny == 0)
+        return fail(ctx, CRT_ERR_INVALID, "bad argument to crt_scatter_shards");
+    int rc = bind(ctx);
+    if (rc != CRT_OK) return rc;
+    crt::launch_scatter(nx, ny, (nx + 7u) / 8u, (ny + 7u) / 8u, world, crt_shard_tiles_max(nx, ny, world),
+                        gathered_dev, fb_dev, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return CRT_OK;
+}
+
+int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!out || !st) return fail(ctx, CRT_ERR_INVALID, "NULL argument");
+    if (!ctx->rng_dev) return fail(ctx, CRT_ERR_NO_RNG, "no RNG states");
+    int rc = bind(ctx);
+    if (rc != CRT_OK) return rc;
+    const size_t npix = (size_t)ctx->rng_nx * ctx->rng_ny;
+    std::vector<uint32_t> d_now(npix), d_init(npix), cnt(npix * 2);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(d_now.data(), ctx->rng_dev + 5 * npix, npix * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(d_init.data(), ctx->rng_init_d, npix * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(cnt.data(), ctx->counters_dev, npix * 8, hipMemcpyDeviceToHost));
+    uint64_t draws = 0, shade = 0, expand = 0;
+    for (size_t p = 0; p < npix; ++p) {
+        draws += (uint32_t)((d_now[p] - d_init[p]) * 945708813u); // 362437^-1 mod 2^32
+        shade += cnt[p];
+        expand += cnt[npix + p];
+    }
+    out->rng_draws = draws;
+    out->shade_points = shade;
+    out->gi_children = expand * (uint64_t)st->ind_rays;
+    out->shadow_samples = (draws - 2u * out->gi_children) / 2u;
+    return CRT_OK;
+}
+
+int crt_fb_alloc(crt_ctx* ctx, size_t n_floats, float** out_dev) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!out_dev || n_floats == 0) return fail(ctx, CRT_ERR_INVALID, "bad argument to crt_fb_alloc");
+    int rc = bind(ctx);
+    if (rc != CRT_OK) return rc;
+    HIP_TRY(ctx, hipMalloc((void**)out_dev, n_floats * sizeof(float)));
+    return CRT_OK;
+}
+
+int crt_fb_free(crt_ctx* ctx, float* dev) {
+    if (!ctx) return CRT_ERR_INVALID;
+    int rc = bind(ctx);
+    if (rc != CRT_OK) return rc;
+    HIP_TRY(ctx, hipFree(dev));
+    return CRT_OK;
+}
+
+int crt_fb_download(crt_ctx* ctx, const float* dev, float* host, size_t n_floats, void* stream) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!dev || !host) return fail(ctx, CRT_ERR_INVALID, "NULL buffer");
+    int rc = bind(ctx);
+    if (rc != CRT_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(host, dev, n_floats * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return CRT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,391 @@
+// Device-side building blocks of the per-pixel render path for gfx950.
+//
+// One lane owns one pixel and walks that pixel's sample tree in the reference's
+// order, so the pixel's XORWOW stream is consumed draw for draw as the reference
+// consumes it.  All arithmetic is IEEE binary32 evaluated in the reference's
+// expression order without contraction (the build passes -ffp-contract=off);
+// per-primitive quantities that the reference recomputes per ray are read from
+// the flattened scene instead (crt_scene.hpp) -- same operations on the same
+// inputs, so the same bits.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "crt_scene.hpp"
+
+#define DI __device__ __forceinline__
+
+namespace crt {
+
+constexpr float kEps = 1e-4f;   // MSTD_CUDA_EPSILON (math_types.hpp:78)
+constexpr float kEpsSq = 1e-8f; // MSTD_CUDA_EPSILON_SQ (math_types.hpp:79)
+constexpr float kFltMax = 3.402823466e+38f;
+
+struct V3 {
+    float x, y, z;
+};
+struct V4 {
+    float x, y, z, w;
+};
+
+DI V3 mk3(float x, float y, float z) { return V3{x, y, z}; }
+DI V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+DI V4 ld4(const float* p) { return V4{p[0], p[1], p[2], p[3]}; }
+DI V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+DI V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+DI V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+DI V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+DI V3 neg(V3 a) { return a * -1.0f; } // vec::operator-() multiplies by -1 (vec.hpp:819-821)
+DI V4 operator+(V4 a, V4 b) { return V4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+DI V4 operator*(V4 a, V4 b) { return V4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+DI V4 operator*(V4 a, float s) { return V4{a.x * s, a.y * s, a.z * s, a.w * s}; }
+DI bool equal4(V4 a, V4 b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; }
+DI float comp(V3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// vec::dot accumulates from zero in index order (vec.hpp:428-434).
+DI float dot3(V3 a, V3 b) {
+    float r = 0.0f + a.x * b.x;
+    r = r + a.y * b.y;
+    r = r + a.z * b.z;
+    return r;
+}
+DI float len_sq(V3 a) { return dot3(a, a); }
+DI float rsqrt_c(float x) { return 1.0f / __builtin_sqrtf(x); } // rsqrtf in IEEE form
+DI float length3(V3 a) { return 1.0f / rsqrt_c(len_sq(a)); }    // vec.hpp:398-409
+// vec::operator/=(T) (vec.hpp:739-769)
+DI V3 div_s(V3 a, float y) {
+    if (y == 0.0f) return a;
+    float inv = 1.0f / y;
+    return a * inv;
+}
+// vec::normalize (vec.hpp:411-422)
+DI V3 normalize3(V3 a) {
+    float len = length3(a);
+    if (len == 0.0f) return a;
+    float inv = 1.0f / len;
+    return a * inv;
+}
+DI V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+DI bool eps_equal(float a, float b, float e) { return __builtin_fabsf(a - b) < e; } // math_functions.hpp:75-78
+DI float min_std(float a, float b) { return (b < a) ? b : a; }                      // cuda::std::min
+DI float max_std(float a, float b) { return (a < b) ? b : a; }                      // cuda::std::max
+DI float saturate_c(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
+// vec::reflect (vec.hpp:460-468)
+DI V3 reflect3(V3 i, V3 n) {
+    float k = 2.0f * dot3(i, n);
+    return i - n * k;
+}
+// vec::refracted, device branch (vec.hpp:475-491)
+DI V3 refract3(V3 d, V3 n, float eta) {
+    float cos_theta = min_std(dot3(neg(d), n), 1.0f);
+    V3 perp = (d + n * cos_theta) * eta;
+    float lsq = len_sq(perp);
+    V3 par = div_s(neg(n), rsqrt_c(__builtin_fabsf(1.0f - lsq)));
+    return perp + par;
+}
+
+// ---------------------------------------------------------------- XORWOW (cuRAND)
+// State words {v0..v4, d}; next() is curand(), uniform() is curand_uniform()
+// (main.cu:177-178,324; AreaLight.hpp:342-343).
+struct Rng {
+    uint32_t v0, v1, v2, v3, v4, d;
+};
+DI void rng_seed(Rng& s, uint64_t seed) {
+    uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
+    uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0;
+    uint32_t t1 = 2591861531u * s1;
+    s.d = 6615241u + t1 + t0;
+    s.v0 = 123456789u + t0;
+    s.v1 = 362436069u ^ t0;
+    s.v2 = 521288629u + t1;
+    s.v3 = 88675123u ^ t1;
+    s.v4 = 5783321u + t0;
+}
+DI void rng_step(Rng& s) {
+    uint32_t t = s.v0 ^ (s.v0 >> 2);
+    s.v0 = s.v1;
+    s.v1 = s.v2;
+    s.v2 = s.v3;
+    s.v3 = s.v4;
+    s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+    s.d += 362437u;
+}
+DI float rng_to_uniform(uint32_t x) { return (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f); }
+DI float rng_uniform(Rng& s) {
+    rng_step(s);
+    return rng_to_uniform(s.v4 + s.d);
+}
+// Value the generator returned when it arrived in state s.
+DI float rng_current_uniform(const Rng& s) { return rng_to_uniform(s.v4 + s.d); }
+// Exact inverse of rng_step (the xorshift is a bijection on the five words).
+DI void rng_unstep(Rng& s) {
+    uint32_t y = s.v4 ^ (s.v3 ^ (s.v3 << 4)); // = t ^ (t << 1)
+    uint32_t t = y;
+    t ^= t << 1;
+    t ^= t << 2;
+    t ^= t << 4;
+    t ^= t << 8;
+    t ^= t << 16;
+    uint32_t u = t; // t = u ^ (u >> 2)
+    u ^= u >> 2;
+    u ^= u >> 4;
+    u ^= u >> 8;
+    u ^= u >> 16;
+    s.v4 = s.v3;
+    s.v3 = s.v2;
+    s.v2 = s.v1;
+    s.v1 = s.v0;
+    s.v0 = u;
+    s.d -= 362437u;
+}
+
+// ------------------------------------------------------------------ sin / cos
+// Stand-in for __sinf/__cosf on [0, 2*pi] (main.cu:64-65): two-term Cody-Waite
+// reduction by pi/2 and fixed polynomial kernels, mul/add only, so the host
+// checker can reproduce it bit for bit.  |error| < 2e-7.
+DI void sincos_c(float a, float& s, float& c) {
+    const float TWO_OVER_PI = 0.63661977236758134308f;
+    const float PIO2_1 = 1.5707855225e+00f;
+    const float PIO2_1T = 1.0804334124e-05f;
+    float kf = __builtin_floorf(a * TWO_OVER_PI + 0.5f);
+    int k = (int)kf;
+    float r = a - kf * PIO2_1;
+    r = r - kf * PIO2_1T;
+    float z = r * r;
+    const float S1 = -1.6666667163e-01f, S2 = 8.3333337680e-03f, S3 = -1.9841270114e-04f, S4 = 2.7557314297e-06f;
+    const float C1 = 4.1666667908e-02f, C2 = -1.3888889225e-03f, C3 = 2.4801587642e-05f;
+    float ps = S3 + z * S4;
+    ps = S2 + z * ps;
+    ps = S1 + z * ps;
+    float sr = r + (r * z) * ps;
+    float pc = C2 + z * C3;
+    pc = C1 + z * pc;
+    float cr = (1.0f - 0.5f * z) + (z * z) * pc;
+    switch (k & 3) {
+        case 0: s = sr; c = cr; break;
+        case 1: s = cr; c = -sr; break;
+        case 2: s = -sr; c = -cr; break;
+        default: s = -cr; c = sr; break;
+    }
+}
+
+// ------------------------------------------------------------ intersection tests
+// Sphere::hit (Sphere.hpp:40-98): returns the accepted root in t.  dd = d.d.
+DI bool sphere_t(const DevGeom& g, V3 o, V3 d, float dd, float dist, float& t) {
+    V3 L = o - ld3(g.center);
+    float a = dd;
+    float b = 2.0f * dot3(d, L);
+    float c = dot3(L, L) - g.radius_sq;
+    float discr = b * b - 4.0f * a * c;
+    if (discr < 0.0f) return false;
+    float t0, t1;
+    if (eps_equal(discr, 0.0f, kEps)) {
+        t0 = t1 = -0.5f * (b / a);
+    } else {
+        float sq = 1.0f / rsqrt_c(discr);
+        float q = (b > 0.0f) ? -0.5f * (b + sq) : -0.5f * (b - sq);
+        t0 = q / a;
+        t1 = c / q;
+    }
+    if (t0 > t1) {
+        float tmp = t0;
+        t0 = t1;
+        t1 = tmp;
+    }
+    if (t0 < 0.0f) {
+        t0 = t1;
+        if (t0 < 0.0f) return false;
+    }
+    if (dist > 0.0f && t0 > dist) return false;
+    t = t0;
+    return true;
+}
+
+// Bilinear-quad test shared by Quad::hit (Quad.hpp:196-295) and
+// AreaLight::_hittedLight (AreaLight.hpp:378-481).  p = ray origin relative to
+// corner 0.  LIGHT selects _hittedLight's 0.5f * (1/k2) (AreaLight.hpp:456).
+template <bool LIGHT, class Q>
+DI bool quad_tuv(const Q& g, V3 p, V3 d, float dist, float& t, float& u, float& v) {
+    V3 nor = ld3(g.nor);
+    float tt = -(dot3(p, nor) / dot3(d, nor));
+    if (tt < 0.0f || (dist > 0.0f && tt > dist)) return false;
+    V3 pos = p + d * tt;
+    float kpx = comp(pos, g.idu), kpy = comp(pos, g.idv);
+    float kax = g.ka[0], kay = g.ka[1], kbx = g.kb[0], kby = g.kb[1], kgx = g.kg[0], kgy = g.kg[1];
+    float k0 = kpx * kby - kpy * kbx;
+    float k2 = g.k2;
+    float k1 = (kpx * kgy - kpy * kgx) - g.nor_id;
+    float uu, vv;
+    if (g.linear) {
+        vv = -(k0 / k1);
+        uu = (kpx * kay - kpy * kax) / k1;
+    } else {
+        float w = k1 * k1 - 4.0f * k0 * k2;
+        if (w < 0.0f) return false;
+        w = 1.0f / rsqrt_c(w);
+        float ik2 = LIGHT ? 0.5f * (1.0f / k2) : 1.0f / (2.0f * k2);
+        vv = (-k1 - w) * ik2;
+        if (vv < 0.0f || vv > 1.0f) vv = (-k1 + w) * ik2;
+        uu = (kpx - kax * vv) / (kbx + kgx * vv);
+    }
+    if (min_std(uu, vv) < 0.0f || max_std(uu, vv) > 1.0f) return false;
+    t = tt;
+    u = uu;
+    v = vv;
+    return true;
+}
+
+struct Hit {
+    int idx; // -1: nothing hit
+    float t, u, v;
+};
+
+// GeometryList::hit (GeometryList.hpp:22-35): closest hit, ties and unordered
+// distances go to the later primitive.
+DI Hit closest_hit(const DevScene* __restrict__ sc, V3 o, V3 d, float dist) {
+    Hit h;
+    h.idx = -1;
+    h.t = kFltMax;
+    h.u = 0.0f;
+    h.v = 0.0f;
+    const float dd = dot3(d, d);
+    const uint32_t n = sc->n_geom;
+    for (uint32_t i = 0; i < n; ++i) {
+        const DevGeom& g = sc->geom[i];
+        float t, u = 0.0f, v = 0.0f;
+        bool hit;
+        if (g.kind == CRT_GEOM_SPHERE) hit = sphere_t(g, o, d, dd, dist, t);
+        else hit = quad_tuv<false>(g, o - ld3(g.v0), d, dist, t, u, v);
+        if (hit && !(t > h.t)) {
+            h.idx = (int)i;
+            h.t = t;
+            h.u = u;
+            h.v = v;
+        }
+    }
+    return h;
+}
+
+// Hit point and shading normal of an accepted hit (Sphere.hpp:102-107, Quad.hpp:299-325).
+DI void hit_point_normal(const DevScene* __restrict__ sc, const Hit& h, V3 o, V3 d, V3& P, V3& N) {
+    const DevGeom& g = sc->geom[h.idx];
+    P = o + d * h.t;
+    if (g.kind == CRT_GEOM_SPHERE) {
+        N = normalize3(P - ld3(g.center));
+    } else {
+        float u = h.u, v = h.v;
+        float l0 = (1 - u) * (1 - v);
+        float l1 = u * (1 - v);
+        float l2 = u * v;
+        float l3 = (1 - u) * v;
+        N = V3{l0 * g.n[0][0] + l1 * g.n[1][0] + l2 * g.n[2][0] + l3 * g.n[3][0],
+               l0 * g.n[0][1] + l1 * g.n[1][1] + l2 * g.n[2][1] + l3 * g.n[3][1],
+               l0 * g.n[0][2] + l1 * g.n[1][2] + l2 * g.n[2][2] + l3 * g.n[3][2]};
+    }
+}
+
+// Ray(origin, dir) keeps dir as given when it is shorter than 1e-4, else normalises (Ray.hpp:37-43).
+DI V3 ray_dir(V3 d) { return eps_equal(len_sq(d), 0.0f, kEpsSq) ? d : normalize3(d); }
+
+// Glass on the way to the light: the part of Light::_isCovered (Light.hpp:47-80)
+// entered when the closest hit is Refractive.  Returns "covered".
+DI bool covered_through_glass(const DevScene* __restrict__ sc, const DevLight& L, V3 o, V3 d, Hit h) {
+    // The do/while of the reference runs at most `iterations` = 10 passes; pass 0 found h.
+    for (unsigned i = 0;;) {
+        const DevGeom& g = sc->geom[h.idx];
+        V3 P, N;
+        hit_point_normal(sc, h, o, d, P, N);
+        bool front_face = dot3(d, N) < 0.0f;
+        V3 norm = front_face ? N : neg(N);
+        float ratio = g.refract_index / 1.0f;
+        if (front_face) ratio = 1.0f / ratio;
+        V3 rd = normalize3(d);
+        float cos_theta = __builtin_fminf(dot3(neg(rd), norm), 1.0f);
+        float sin_theta = 1.0f / rsqrt_c(1.0f - cos_theta * cos_theta);
+        // reflectance(...) > 1.0f (Light.hpp:61) cannot hold for cos_theta in [0,1]; only the TIR test remains.
+        if (ratio * sin_theta > 1.0f) return true;
+        V3 dir = refract3(rd, norm, ratio);
+        V3 ro = P + dir * 0.01f;
+        V3 rdir = ray_dir(dir);
+        if (!front_face) {
+            if (L.kind == CRT_LIGHT_AREA) {
+                float t, u, v;
+                V3 p = (ro - ld3(L.p[0])) - ld3(L.pos);
+                return !quad_tuv<true>(L, p, rdir, 0.0f, t, u, v);
+            } else { // Ray::isPointOnRay (Ray.hpp:80-105) with distance 0
+                V3 w = ld3(L.pos) - ro;
+                V3 cr = cross3(rdir, w);
+                if (len_sq(cr) >= kEpsSq) return true;
+                return !(dot3(w, rdir) >= 0.0f);
+            }
+        }
+        o = ro;
+        d = rdir;
+        ++i;
+        if (!(i < 10u)) return true; // loop ends with hit.isHit still set
+        h = closest_hit(sc, o, d, 0.0f);
+        if (h.idx < 0) return false;
+        if (sc->geom[h.idx].mat_type != CRT_MAT_REFRACTIVE) return true;
+    }
+}
+
+// Light::_isCovered (Light.hpp:35-86) for a shadow ray.
+DI bool is_covered(const DevScene* __restrict__ sc, const DevLight& L, V3 o, V3 d, float dist) {
+    Hit h = closest_hit(sc, o, d, dist);
+    if (h.idx < 0) return false;
+    if (sc->geom[h.idx].mat_type != CRT_MAT_REFRACTIVE) return true;
+    return covered_through_glass(sc, L, o, d, h);
+}
+
+// ------------------------------------------------------------------ LTC shading
+// Texture::sample row coordinate with CLAMP wrap (Texture.hpp:154-182); 64 = out of range.
+DI uint32_t ltc_texel(float f) {
+    if (f < 0.0f || f > 1.0f) f = saturate_c(f);
+    uint32_t i = (uint32_t)(f * 63.0f);
+    return i < 64u ? i : 64u;
+}
+
+// AreaLight::_integrateEdgeVec (AreaLight.hpp:72-98)
+DI V3 integrate_edge_vec(V3 v1, V3 v2) {
+    float x = dot3(v1, v2);
+    float y = __builtin_fabsf(x);
+    float a = 0.8543985f + (0.4965155f + 0.0145206f * y) * y;
+    float b = 3.4175940f + (4.1616724f + y) * y;
+    float v = a / b;
+    float ts = (x > 0.0f) ? v : 0.5f * rsqrt_c(max_std(1.0f - x * x, kEps)) - v;
+    return cross3(v1, v2) * ts;
+}
+
+// Tail of AreaLight::_evaluateLTC's clipless branch (AreaLight.hpp:254-297) on the four transformed corners.
+DI float ltc_polygon(const float* __restrict__ ltc2, V3 L0, V3 L1, V3 L2, V3 L3, bool behind, bool two_sided) {
+    L0 = ray_dir(L0); // same "normalise unless shorter than 1e-4" rule as Ray
+    L1 = ray_dir(L1);
+    L2 = ray_dir(L2);
+    L3 = ray_dir(L3);
+    V3 vsum = mk3(0.0f, 0.0f, 0.0f);
+    vsum = vsum + integrate_edge_vec(L0, L1);
+    vsum = vsum + integrate_edge_vec(L1, L2);
+    vsum = vsum + integrate_edge_vec(L2, L3);
+    vsum = vsum + integrate_edge_vec(L3, L0);
+    float len = length3(vsum);
+    float z = !eps_equal(len, 0.0f, kEps) ? vsum.z / len : 0.0f;
+    if (behind) z = -z;
+    const float LUT_SCALE = 63.0f / 64.0f, LUT_BIAS = 0.5f / 64.0f; // AreaLight.hpp:47-49
+    float ux = (z * 0.5f + 0.5f) * LUT_SCALE + LUT_BIAS;
+    float uy = len * LUT_SCALE + LUT_BIAS;
+    uint32_t tx = ltc_texel(ux), ty = ltc_texel(uy);
+    float scale = (tx < 64u && ty < 64u) ? ltc2[(ty * 64u + tx) * 4u + 3u] : 0.0f;
+    float sum = len * scale;
+    if (!behind && !two_sided) sum = 0.0f;
+    return sum;
+}
+
+// main.cu:50-58
+DI void surface_frame(V3 n, V3& Nx, V3& Nz) {
+    if (__builtin_fabsf(n.x) > __builtin_fabsf(n.y)) Nx = mk3(n.z, 0.0f, -n.x) * rsqrt_c(n.x * n.x + n.z * n.z);
+    else Nx = mk3(0.0f, -n.z, n.y) * rsqrt_c(n.y * n.y + n.z * n.z);
+    Nz = cross3(n, Nx);
+}
+
+} // namespace crt

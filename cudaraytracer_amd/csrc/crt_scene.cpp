@@ -1,0 +1,221 @@
+// Host side of the scene boundary: the Cornell box factory and the flattening of
+// a crt_scene_desc into the device-resident DevScene.  Compiled for the host
+// only, IEEE binary32, no contraction (see Makefile: -ffp-contract=off).
+#include "crt_scene.hpp"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../include/craytracer/craytracer.hpp"
+
+namespace crt {
+
+namespace {
+
+struct F3 {
+    float x, y, z;
+};
+inline F3 ld(const float* p) { return {p[0], p[1], p[2]}; }
+inline void st(float* p, F3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+inline F3 sub(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline F3 add(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline F3 cross(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float comp(F3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+inline float lensq(F3 a) {
+    float r = 0.0f;
+    r += a.x * a.x;
+    r += a.y * a.y;
+    r += a.z * a.z;
+    return r;
+}
+// mstd length()/normalize() (vec.hpp:398-422): 1/(1/sqrt), multiply by 1/len
+inline F3 normalize(F3 a) {
+    float len = 1.0f / (1.0f / sqrtf(lensq(a)));
+    if (len == 0.0f) return a;
+    float inv = 1.0f / len;
+    return {a.x * inv, a.y * inv, a.z * inv};
+}
+
+// The vertex-only part of the bilinear quad test (Quad.hpp:202-250, AreaLight.hpp:382-432).
+struct QuadConst {
+    F3 a, b, nor;
+    uint32_t id, idu, idv;
+    float ka[2], kb[2], kg[2], k2, nor_id;
+    uint32_t linear;
+};
+QuadConst quad_constants(F3 p0, F3 p1, F3 p2, F3 p3) {
+    static const uint32_t lut[4] = {1, 2, 0, 1};
+    QuadConst q;
+    q.a = sub(p1, p0);
+    q.b = sub(p3, p0);
+    F3 c = sub(p2, p0);
+    q.nor = cross(q.a, q.b);
+    float mx = fabsf(q.nor.x), my = fabsf(q.nor.y), mz = fabsf(q.nor.z);
+    q.id = (mx > my && mx > mz) ? 0u : (my > mz) ? 1u : 2u;
+    q.idu = lut[q.id];
+    q.idv = lut[q.id + 1];
+    float kcx = comp(c, q.idu), kcy = comp(c, q.idv);
+    q.ka[0] = comp(q.a, q.idu);
+    q.ka[1] = comp(q.a, q.idv);
+    q.kb[0] = comp(q.b, q.idu);
+    q.kb[1] = comp(q.b, q.idv);
+    q.kg[0] = (kcx - q.kb[0]) - q.ka[0];
+    q.kg[1] = (kcy - q.kb[1]) - q.ka[1];
+    float kcbx = kcx - q.kb[0], kcby = kcy - q.kb[1];
+    q.k2 = kcbx * q.ka[1] - kcby * q.ka[0];
+    q.nor_id = comp(q.nor, q.id);
+    q.linear = fabsf(q.k2 - 0.0f) < 1e-4f ? 1u : 0u;
+    return q;
+}
+
+void fail(char* err, size_t cap, const char* msg) {
+    if (err && cap) snprintf(err, cap, "%s", msg);
+}
+
+} // namespace
+
+int flatten_scene(const crt_scene_desc* in, DevScene* out, const float* /*ltc_tables*/, char* err, size_t errcap) {
+    if (!in || !out) {
+        fail(err, errcap, "flatten_scene: null argument");
+        return CRT_ERR_INVALID;
+    }
+    if (in->n_geometry > CRT_MAX_GEOMETRY || (in->n_geometry && !in->geometry)) {
+        fail(err, errcap, "scene: n_geometry exceeds CRT_MAX_GEOMETRY or geometry is NULL");
+        return CRT_ERR_INVALID;
+    }
+    if (in->n_lights > CRT_MAX_LIGHTS || (in->n_lights && !in->lights)) {
+        fail(err, errcap, "scene: n_lights exceeds CRT_MAX_LIGHTS or lights is NULL");
+        return CRT_ERR_INVALID;
+    }
+    memset(out, 0, sizeof *out);
+
+    // Camera (Camera.hpp:86-141)
+    const crt_camera& c = in->camera;
+    if (c.type != CRT_CAM_ORTHOGRAPHIC && c.type != CRT_CAM_PERSPECTIVE) {
+        fail(err, errcap, "scene: unknown camera type");
+        return CRT_ERR_INVALID;
+    }
+    F3 front = ld(c.front);
+    F3 right = normalize(cross(front, F3{0.0f, 1.0f, 0.0f}));
+    F3 up = normalize(cross(right, front));
+    st(out->cam.pos, ld(c.pos));
+    st(out->cam.front, front);
+    st(out->cam.right, right);
+    st(out->cam.up, up);
+    out->cam.one_over_tan = 1.0f / tanf(c.fov * 0.5f);
+    out->cam.ortho_scale = c.orthoScale;
+    out->cam.type = c.type;
+
+    const float LUT_SCALE = (64.0f - 1.0f) / 64.0f, LUT_BIAS = 0.5f / 64.0f; // AreaLight.hpp:47-49
+    out->n_geom = in->n_geometry;
+    for (uint32_t i = 0; i < in->n_geometry; ++i) {
+        const crt_geometry& g = in->geometry[i];
+        DevGeom& d = out->geom[i];
+        if (g.kind != CRT_GEOM_SPHERE && g.kind != CRT_GEOM_QUAD) {
+            fail(err, errcap, "scene: unknown geometry kind");
+            return CRT_ERR_INVALID;
+        }
+        if (g.mat.type > CRT_MAT_REFRACTIVE) {
+            fail(err, errcap, "scene: unknown material type");
+            return CRT_ERR_INVALID;
+        }
+        d.kind = g.kind;
+        d.mat_type = g.mat.type;
+        memcpy(d.ambient, g.mat.ambient, 16);
+        memcpy(d.diffuse, g.mat.diffuse, 16);
+        memcpy(d.specular, g.mat.specular, 16);
+        d.refract_index = g.mat.refractIndex;
+        d.shininess = g.mat.shininess;
+        // roughness -> LTC texel column (AreaLight.hpp:608,619,625; Texture.hpp:126-152,179-182)
+        float roughness = 1.0f - 0.25f * powf(g.mat.shininess, 0.2f);
+        float u = roughness * LUT_SCALE + LUT_BIAS;
+        if (u < 0.0f || u > 1.0f) u = fminf(fmaxf(u, 0.0f), 1.0f);
+        float fx = u * 63.0f;
+        uint32_t col = (fx >= 0.0f && fx < 4294967296.0f) ? (uint32_t)fx : 0xFFFFFFFFu;
+        d.ltc_col = col < 64u ? col : 0xFFFFFFFFu; // out of range -> getPixelColor returns zeros
+        if (g.kind == CRT_GEOM_SPHERE) {
+            memcpy(d.center, g.center, 12);
+            d.radius = g.radius;
+            d.radius_sq = g.radius * g.radius;
+        } else {
+            F3 p0 = ld(g.v[0].pos);
+            QuadConst q = quad_constants(p0, ld(g.v[1].pos), ld(g.v[2].pos), ld(g.v[3].pos));
+            st(d.v0, p0);
+            st(d.a, q.a);
+            st(d.b, q.b);
+            st(d.nor, q.nor);
+            d.id = q.id;
+            d.idu = q.idu;
+            d.idv = q.idv;
+            memcpy(d.ka, q.ka, 8);
+            memcpy(d.kb, q.kb, 8);
+            memcpy(d.kg, q.kg, 8);
+            d.k2 = q.k2;
+            d.nor_id = q.nor_id;
+            d.linear = q.linear;
+            for (int k = 0; k < 4; ++k) memcpy(d.n[k], g.v[k].normal, 12);
+        }
+    }
+
+    out->n_lights = in->n_lights;
+    for (uint32_t i = 0; i < in->n_lights; ++i) {
+        const crt_light& l = in->lights[i];
+        DevLight& d = out->lights[i];
+        if (l.kind != CRT_LIGHT_AREA && l.kind != CRT_LIGHT_POINT) {
+            fail(err, errcap, "scene: unknown light kind");
+            return CRT_ERR_INVALID;
+        }
+        d.kind = l.kind;
+        memcpy(d.pos, l.pos, 12);
+        memcpy(d.color, l.color, 12);
+        d.intensity = l.intensity;
+        d.two_sided = l.twoSided;
+        d.shadow_samples = l.shadowSamples;
+        d.initialized = l.initialized;
+        if (l.kind == CRT_LIGHT_AREA) {
+            F3 pos = ld(l.pos);
+            F3 p[4], w[4];
+            for (int k = 0; k < 4; ++k) {
+                p[k] = ld(l.points[k]);
+                w[k] = add(pos, p[k]);
+                st(d.p[k], p[k]);
+                st(d.pts[k], w[k]);
+            }
+            st(d.e01, sub(p[1], p[0]));
+            st(d.e03, sub(p[3], p[0]));
+            st(d.e23, sub(p[3], p[2]));
+            st(d.e21, sub(p[1], p[2]));
+            st(d.light_normal, cross(sub(w[1], w[0]), sub(w[3], w[0])));
+            QuadConst q = quad_constants(p[0], p[1], p[2], p[3]);
+            st(d.a, q.a);
+            st(d.b, q.b);
+            st(d.nor, q.nor);
+            d.id = q.id;
+            d.idu = q.idu;
+            d.idv = q.idv;
+            memcpy(d.ka, q.ka, 8);
+            memcpy(d.kb, q.kb, 8);
+            memcpy(d.kg, q.kg, 8);
+            d.k2 = q.k2;
+            d.nor_id = q.nor_id;
+            d.linear = q.linear;
+        }
+    }
+    return CRT_OK;
+}
+
+} // namespace crt
+
+// create_world (main.cu:370-595) restated through the host-side scene classes.
+extern "C" int crt_cornell_scene(uint32_t shadowSamples, crt_camera* camera, crt_geometry* geometry8,
+                                 crt_light* light1) {
+    if (!camera || !geometry8 || !light1) return CRT_ERR_INVALID;
+    craytracer::CornellBox box(shadowSamples);
+    craytracer::FlatScene flat = craytracer::flatten(box.camera, box.world, box.lights);
+    if (flat.geometry.size() != 8 || flat.lights.size() != 1) return CRT_ERR_INVALID;
+    *camera = flat.camera;
+    for (size_t i = 0; i < 8; ++i) geometry8[i] = flat.geometry[i];
+    *light1 = flat.lights[0];
+    return CRT_OK;
+}

@@ -1,0 +1,29 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    oracle_lib.lib()
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """One context on cuda:0 shared by the GPU tests (fails loudly without the HIP library or a GPU)."""
+    import cudaraytracer_amd as crt
+    ctx = crt.Context(0)
+    yield ctx
+    ctx.close()

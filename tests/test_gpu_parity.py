@@ -1,0 +1,83 @@
+"""HIP render path vs the CPU restatement (oracle/), through the C ABI.
+
+Bar: the path is FP32.  north_star asks for per-pixel max-abs <= 1e-4 at
+gl_iter=0 and mean-relative <= 1e-3 at gl_iter>=1 with matched RNG streams.
+Both sides evaluate the same IEEE expression tree, so these tests assert the
+stronger property -- identical floats and identical final RNG states (i.e. the
+same sample tree, draw for draw) -- and keep the stated tolerances as the
+documented fallback bound.
+"""
+import numpy as np
+import pytest
+
+import cudaraytracer_amd as crt
+
+pytestmark = pytest.mark.gpu
+
+TOL_GL0_MAXABS = 1e-4
+TOL_GL1_MEANREL = 1e-3
+
+
+def _gpu_render(ctx, scene, st, seed, progressive=False):
+    ctx.upload(scene)
+    ctx.rng_init(st.nx, st.ny, seed)
+    fb = ctx.render_to_host(st, progressive=progressive)
+    state = ctx.rng_export(st.nx, st.ny)
+    return fb, state
+
+
+def _compare(fb, ref, state, ref_state, gl):
+    diff = np.abs(fb.astype(np.float64) - ref.astype(np.float64))
+    if gl == 0:
+        assert diff.max() <= TOL_GL0_MAXABS, f"max abs {diff.max()}"
+    else:
+        rel = diff.sum() / max(np.abs(ref).sum(), 1e-30)
+        assert rel <= TOL_GL1_MEANREL, f"mean rel {rel}"
+    # the stronger, structural claim
+    assert np.array_equal(state, ref_state), "final RNG states differ: sample trees diverged"
+    assert np.array_equal(fb, ref), f"not bit-identical: {np.count_nonzero(fb != ref)} floats differ, max {diff.max()}"
+
+
+@pytest.mark.parametrize("n,aa,gl,ind,S", [
+    (64, 1, 0, 75, 50),   # BASELINE configs[0] shape at reduced size
+    (48, 0, 0, 75, 50),
+    (40, 2, 0, 75, 20),
+    (24, 4, 0, 75, 10),   # deepest adaptive AA
+    (32, 1, 1, 75, 50),
+    (24, 1, 1, 7, 5),
+    (10, 1, 2, 75, 50),   # 128-entry stack truncation (54 of 75 children accepted)
+    (12, 1, 3, 6, 4),     # three nested GI levels
+    (16, 0, 4, 3, 2),
+])
+def test_cornell_matches_oracle(gpu_ctx, oracle, n, aa, gl, ind, S):
+    st = crt.make_settings(nx=n, ny=n, aa_iter=aa, gl_iter=gl, ind_rays=ind, shadowSamples=S)
+    scene = crt.cornell_box(S)
+    fb, state = _gpu_render(gpu_ctx, scene, st, 1234)
+    ref, cnt, ref_state = oracle.render(oracle.cornell(S), st, 1234, want_state=True)
+    _compare(fb, ref, state, ref_state, gl)
+    stats = gpu_ctx.stats(st)
+    assert stats.rng_draws == cnt.rng_draws
+    assert stats.shade_points == cnt.shade_points
+    assert stats.gi_children == cnt.gi_children
+
+
+def test_non_square_and_ragged_tiles(gpu_ctx, oracle):
+    st = crt.make_settings(nx=37, ny=21, aa_iter=1, gl_iter=0, shadowSamples=12)
+    fb, state = _gpu_render(gpu_ctx, crt.cornell_box(12), st, 99)
+    ref, _, ref_state = oracle.render(oracle.cornell(12), st, 99, want_state=True)
+    _compare(fb, ref, state, ref_state, 0)
+
+
+def test_second_render_continues_streams(gpu_ctx, oracle):
+    st = crt.make_settings(nx=32, ny=32, aa_iter=1, gl_iter=0, shadowSamples=8)
+    scene = crt.cornell_box(8)
+    gpu_ctx.upload(scene)
+    gpu_ctx.rng_init(32, 32, 5)
+    a = gpu_ctx.render_to_host(st)
+    b = gpu_ctx.render_to_host(st)
+    osc = oracle.cornell(8)
+    ra, _, s1 = oracle.render(osc, st, 5, want_state=True)
+    rb, _, s2 = oracle.render(osc, st, 5, rng_state=s1)
+    assert np.array_equal(a, ra) and np.array_equal(b, rb)
+    assert not np.array_equal(a, b)
+    assert np.array_equal(gpu_ctx.rng_export(32, 32), s2)
