@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-pixel render path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload gl0|gl1|gl2]
+
+A step is one render of the README's 720x720 Cornell box (aa_iter=1, ref_iter=4,
+ind_rays=75, shadowSamples=50; main.cu:626-636) at the workload's gl_iter, with
+the scene, LTC tables, RNG states and framebuffer resident in HBM.  With N>1 the
+image is sharded as interleaved 8x8 tiles, one rank per GPU, one RCCL gather to
+rank 0 per step (total work fixed => "strong" scaling).  Rank 0 prints one JSON
+line; `value` is shadow samples per second over all GPUs (Msamples/s) and
+`ms_per_step` the render time the README table quotes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+# README.md:131-133 of the reference (RTX 4070 Ti SUPER), seconds per render
+README_4070TIS_S = {"gl0": 0.116, "gl1": 10.438, "gl2": 574.214}
+PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak (256 CU x 4 SIMD-32 x 2 flop x 2.4 GHz)
+
+
+def algorithmic_flops(stats):
+    """FLOPs of the reference's arithmetic as written: 300 per shadow sample, 1200 per shaded
+    point (closest hit + LTC shading), 40 per generated GI child."""
+    return 300.0 * stats["shadow_samples"] + 1200.0 * stats["shade_points"] + 40.0 * stats["gi_children"]
+
+
+def stats_dict(s):
+    return {"rng_draws": int(s.rng_draws), "shadow_samples": int(s.shadow_samples),
+            "shade_points": int(s.shade_points), "gi_children": int(s.gi_children)}
+
+
+def diff(a, b):
+    return {k: b[k] - a[k] for k in a}
+
+
+def cpu_baseline(workload_gl, budget_s):
+    """Times the CPU restatement (oracle/) on the host cores on a centred crop of the same 720^2 render."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib as O
+    import cudaraytracer_amd as crt
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    crop = {0: 360, 1: 64, 2: 8}[workload_gl]
+    st = crt.make_settings(gl_iter=workload_gl)
+    x0 = (720 - crop) // 2
+    sc = O.cornell(50)
+    t0 = time.perf_counter()
+    _, cnt, _ = O.render(sc, st, 1234, region=(x0, x0, x0 + crop, x0 + crop), threads=threads)
+    dt = time.perf_counter() - t0
+    shadow = (cnt.rng_draws - 2 * cnt.gi_children) // 2
+    return {"value": shadow / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"centred {crop}x{crop} crop of the 720x720 gl_iter={workload_gl} render, seed 1234, "
+                      f"{shadow} shadow samples in {dt:.2f} s (OpenMP, dynamic rows)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["gl0", "gl1", "gl2"], default="gl1")
+    ap.add_argument("--nx", type=int, default=720)
+    ap.add_argument("--ny", type=int, default=720)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-rows", action="store_true", help="skip the extra gl0/gl2 README rows at N=1")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import cudaraytracer_amd as crt
+    from cudaraytracer_amd import distributed as shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    gl = int(args.workload[2])
+    nx, ny = args.nx, args.ny
+    st = crt.make_settings(nx=nx, ny=ny, gl_iter=gl)
+    ctx = crt.Context(local_rank)
+    ctx.upload(crt.cornell_box(st.shadowSamples))
+    stream = torch.cuda.current_stream(dev)
+    ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
+
+    tiles_max = shard.shard_tiles_max(nx, ny, world)
+    fb = torch.empty((ny, nx, 4), dtype=torch.float32, device=dev)
+    compact = torch.empty(tiles_max * 64 * 4, dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        if world == 1:
+            ctx.render(st, fb.data_ptr(), stream.cuda_stream)
+        else:
+            ctx.render_shard(st, rank, world, compact.data_ptr(), stream.cuda_stream)
+            shard.gather_image(compact, nx, ny, ctx, fb)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    s0 = stats_dict(ctx.stats(st))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        if world == 1:
+            ctx.render(st, fb.data_ptr(), stream.cuda_stream)
+            ev[k][1].record(stream)
+        else:
+            ctx.render_shard(st, rank, world, compact.data_ptr(), stream.cuda_stream)
+            ev[k][1].record(stream)
+            shard.gather_image(compact, nx, ny, ctx, fb)
+    sync()
+    elapsed = time.perf_counter() - t0
+    s1 = stats_dict(ctx.stats(st))
+    work = diff(s0, s1)  # this rank's work over the K timed steps
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # render kernel, HIP events on its stream
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        w = torch.tensor([work["shadow_samples"], work["shade_points"], work["gi_children"], work["rng_draws"]],
+                         dtype=torch.int64, device=dev)
+        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+        total = dict(zip(["shadow_samples", "shade_points", "gi_children", "rng_draws"], [int(x) for x in w.tolist()]))
+    else:
+        total = work
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        per_launch = {k: v / args.steps for k, v in work.items()}
+        achieved = algorithmic_flops(per_launch) / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get(f"{args.workload}_n{world}_{nx}x{ny}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Cornell 720x720 render: shadow-sample throughput (render time in ms_per_step)",
+            "value": total["shadow_samples"] / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"Cornell box {nx}x{ny}, aa_iter=1, ref_iter=4, gl_iter={gl}, ind_rays=75, "
+                                   f"shadowSamples=50 (README row {gl})",
+                       "seed": args.seed, "sharding": "interleaved 8x8 tiles, tile % n_gpus, one gather to rank 0"
+                       if world > 1 else "none",
+                       "primary_samples_per_s": nx * ny * 4 / (elapsed / args.steps)},
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "kernel": "crt::render_kernel", "kernel_ms": kernel_ms,
+                         "flops_model": "300*shadow_samples + 1200*shade_points + 40*gi_children (rank 0's launch)"},
+            "work_per_step": {k: v / args.steps for k, v in total.items()},
+        }
+        if nx == 720 and ny == 720:
+            out["speedup_vs_readme_rtx4070tis"] = README_4070TIS_S[args.workload] / (ms_per_step * 1e-3)
+        if world == 1 and not args.no_rows and nx == 720 and ny == 720:
+            rows = {}
+            for other in ("gl0", "gl2"):
+                if other == args.workload:
+                    continue
+                st2 = crt.make_settings(nx=nx, ny=ny, gl_iter=int(other[2]))
+                ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
+                ctx.render(st2, fb.data_ptr(), stream.cuda_stream)  # untimed warm-up
+                torch.cuda.synchronize(dev)
+                ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                ctx.render(st2, fb.data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t1
+                w2 = stats_dict(ctx.stats(st2))
+                rows[other] = {"ms": dt * 1e3, "Msamples_per_s": w2["shadow_samples"] / dt / 1e6,
+                               "tflops_algorithmic": algorithmic_flops(w2) / dt / 1e12,
+                               "speedup_vs_readme_rtx4070tis": README_4070TIS_S[other] / dt}
+            out["readme_rows"] = rows
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(gl, 20.0)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
