@@ -25,6 +25,7 @@ struct crt_ctx {
     uint32_t* rng_dev = nullptr;      // 6 planes of npix words
     uint32_t* rng_init_d = nullptr;   // plane 5 (d) as seeded, for draw counting
     uint32_t* counters_dev = nullptr; // 2 planes of npix words: shade points, expansions
+    uint32_t* unit_counter = nullptr; // work-unit cursor of the persistent render grid
     uint32_t rng_nx = 0, rng_ny = 0;
 };
 
@@ -73,6 +74,7 @@ crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
     a.ltc = ctx->ltc_dev;
     a.rng = ctx->rng_dev;
     a.counters = ctx->counters_dev;
+    a.unit_counter = ctx->unit_counter;
     a.out = out;
     a.nx = st->nx;
     a.ny = st->ny;
@@ -102,7 +104,8 @@ int crt_create(crt_ctx** out, int device) {
     if (ltc_bytes != 2u * 64u * 64u * 4u * sizeof(float) || hipSetDevice(device) != hipSuccess ||
         hipMalloc((void**)&ctx->ltc_dev, ltc_bytes) != hipSuccess ||
         hipMemcpy(ctx->ltc_dev, crt_ltc_tables_blob, ltc_bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc((void**)&ctx->scene_dev, sizeof(crt::DevScene)) != hipSuccess) {
+        hipMalloc((void**)&ctx->scene_dev, sizeof(crt::DevScene)) != hipSuccess ||
+        hipMalloc((void**)&ctx->unit_counter, 256) != hipSuccess) {
         crt_destroy(ctx);
         return CRT_ERR_HIP;
     }
@@ -119,6 +122,7 @@ void crt_destroy(crt_ctx* ctx) {
         (void)hipFree(ctx->rng_dev);
         (void)hipFree(ctx->rng_init_d);
         (void)hipFree(ctx->counters_dev);
+        (void)hipFree(ctx->unit_counter);
     }
     delete ctx;
 }
@@ -128,7 +132,7 @@ const char* crt_last_error(const crt_ctx* ctx) { return ctx ? ctx->err : "null c
 int crt_scene_upload(crt_ctx* ctx, const crt_scene_desc* scene) {
     if (!ctx) return CRT_ERR_INVALID;
     if (!scene) return fail(ctx, CRT_ERR_INVALID, "scene is NULL");
-    int rc = crt::flatten_scene(scene, &ctx->scene_host, nullptr, ctx->err, sizeof ctx->err);
+    int rc = crt::flatten_scene(scene, &ctx->scene_host, ctx->err, sizeof ctx->err);
     if (rc != CRT_OK) return rc;
     if ((rc = bind(ctx)) != CRT_OK) return rc;
     HIP_TRY(ctx, hipDeviceSynchronize()); // no render may still be reading the old scene
@@ -188,8 +192,8 @@ int crt_render(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void* stream
     if ((rc = bind(ctx)) != CRT_OK) return rc;
     crt::RenderArgs a = base_args(ctx, st, fb_dev);
     a.mode = crt::MODE_FULL;
-    crt::launch_render(a, a.tiles_x * a.tiles_y, (hipStream_t)stream);
-    HIP_TRY(ctx, hipGetLastError());
+    a.n_units = a.tiles_x * a.tiles_y;
+    HIP_TRY(ctx, crt::launch_render(a, (hipStream_t)stream));
     return CRT_OK;
 }
 
@@ -219,8 +223,8 @@ int crt_render_partial(crt_ctx* ctx, const crt_settings* st, uint32_t tileIndex,
     a.start_bx = tileIndex % blocksX;
     a.start_by = (tileIndex / blocksX) < blocksY ? (tileIndex / blocksX) : blocksY;
     const uint64_t lanes = (uint64_t)bx * by * st->tx * st->ty;
-    crt::launch_render(a, (uint32_t)((lanes + 63u) / 64u), (hipStream_t)stream);
-    HIP_TRY(ctx, hipGetLastError());
+    a.n_units = (uint32_t)((lanes + 63u) / 64u);
+    HIP_TRY(ctx, crt::launch_render(a, (hipStream_t)stream));
     return CRT_OK;
 }
 
@@ -248,9 +252,11 @@ int crt_render_shard(crt_ctx* ctx, const crt_settings* st, uint32_t rank, uint32
     a.mode = crt::MODE_SHARD;
     a.rank = rank;
     a.world = world;
-    // every rank launches tiles_max waves so that the padded tail is written as zeros
-    crt::launch_render(a, crt_shard_tiles_max(st->nx, st->ny, world), (hipStream_t)stream);
-    HIP_TRY(ctx, hipGetLastError());
+    // padding (pixels outside the image, tiles past this rank's last one) stays zero
+    const uint32_t tiles_max = crt_shard_tiles_max(st->nx, st->ny, world);
+    HIP_TRY(ctx, hipMemsetAsync(compact_dev, 0, (size_t)tiles_max * 256u * sizeof(float), (hipStream_t)stream));
+    a.n_units = crt_shard_tiles(st->nx, st->ny, rank, world);
+    HIP_TRY(ctx, crt::launch_render(a, (hipStream_t)stream));
     return CRT_OK;
 }
 
@@ -289,6 +295,29 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out) {
     out->shade_points = shade;
     out->gi_children = expand * (uint64_t)st->ind_rays;
     out->shadow_samples = (draws - 2u * out->gi_children) / 2u;
+    return CRT_OK;
+}
+
+int crt_selftest_rcp(crt_ctx* ctx, uint64_t* mismatches, uint32_t* first_bad_bits) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!mismatches || !first_bad_bits) return fail(ctx, CRT_ERR_INVALID, "NULL argument");
+    int rc = bind(ctx);
+    if (rc != CRT_OK) return rc;
+    unsigned long long* d_bad = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_bad, 16));
+    uint32_t* d_first = reinterpret_cast<uint32_t*>(d_bad + 1);
+    hipError_t e = hipMemset(d_bad, 0, 8);
+    if (e == hipSuccess) e = hipMemset(d_first, 0xff, 4);
+    if (e == hipSuccess) {
+        crt::launch_selftest_rcp(d_bad, d_first, nullptr);
+        e = hipGetLastError();
+    }
+    unsigned long long bad = 0;
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(first_bad_bits, d_first, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) return fail(ctx, CRT_ERR_HIP, "selftest: %s", hipGetErrorString(e));
+    *mismatches = bad;
     return CRT_OK;
 }
 

@@ -1,12 +1,16 @@
 // Device-side building blocks of the per-pixel render path for gfx950.
 //
-// One lane owns one pixel and walks that pixel's sample tree in the reference's
-// order, so the pixel's XORWOW stream is consumed draw for draw as the reference
-// consumes it.  All arithmetic is IEEE binary32 evaluated in the reference's
-// expression order without contraction (the build passes -ffp-contract=off);
-// per-primitive quantities that the reference recomputes per ray are read from
-// the flattened scene instead (crt_scene.hpp) -- same operations on the same
-// inputs, so the same bits.
+// One lane owns one pixel at a time and walks that pixel's sample tree in the
+// reference's order, so the pixel's XORWOW stream is consumed draw for draw as
+// the reference consumes it.  All arithmetic is IEEE binary32 evaluated in the
+// reference's expression order without contraction (the build passes
+// -ffp-contract=off; the only fused operations are the explicit ones inside
+// rcp_exact, whose result is the correctly rounded quotient).  Per-primitive
+// quantities that the reference recomputes per ray are read from the flattened
+// scene instead (crt_scene.hpp) -- same operations on the same inputs, so the
+// same bits.  Tests that reject a primitive without dividing are conservative:
+// they fire only when the exact quotient is certain to fail the reference's
+// own comparison, and fall through to the exact path otherwise.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,8 +18,13 @@
 #include "crt_scene.hpp"
 
 #define DI __device__ __forceinline__
+// Constant address space: loads through it with a wave-uniform address become scalar loads.
+#define CRT_CONST __attribute__((address_space(4)))
 
 namespace crt {
+
+typedef const DevScene CRT_CONST* ScenePtr;
+typedef const float CRT_CONST* CFloatPtr;
 
 constexpr float kEps = 1e-4f;   // MSTD_CUDA_EPSILON (math_types.hpp:78)
 constexpr float kEpsSq = 1e-8f; // MSTD_CUDA_EPSILON_SQ (math_types.hpp:79)
@@ -30,7 +39,9 @@ struct V4 {
 
 DI V3 mk3(float x, float y, float z) { return V3{x, y, z}; }
 DI V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+DI V3 ld3c(CFloatPtr p) { return V3{p[0], p[1], p[2]}; }
 DI V4 ld4(const float* p) { return V4{p[0], p[1], p[2], p[3]}; }
+DI V4 ld4c(CFloatPtr p) { return V4{p[0], p[1], p[2], p[3]}; }
 DI V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 DI V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 DI V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
@@ -42,6 +53,25 @@ DI V4 operator*(V4 a, float s) { return V4{a.x * s, a.y * s, a.z * s, a.w * s}; 
 DI bool equal4(V4 a, V4 b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; }
 DI float comp(V3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
+// Correctly rounded 1/x.  For |x| in [2^-100, 2^100] a hardware reciprocal
+// estimate (1 ulp) is refined by two fused Newton steps, which yields the
+// IEEE-rounded quotient for every such x (verified exhaustively over all
+// 2^32 bit patterns by crt_selftest); anything else takes the full division.
+DI float rcp_exact(float x) {
+#if CRT_FAST_RCP
+    float ax = __builtin_fabsf(x);
+    if (ax >= 0x1p-100f && ax <= 0x1p100f) {
+        float r = __builtin_amdgcn_rcpf(x);
+        float e = __builtin_fmaf(-x, r, 1.0f);
+        r = __builtin_fmaf(e, r, r);
+        e = __builtin_fmaf(-x, r, 1.0f);
+        r = __builtin_fmaf(e, r, r);
+        return r;
+    }
+#endif
+    return 1.0f / x;
+}
+
 // vec::dot accumulates from zero in index order (vec.hpp:428-434).
 DI float dot3(V3 a, V3 b) {
     float r = 0.0f + a.x * b.x;
@@ -50,19 +80,19 @@ DI float dot3(V3 a, V3 b) {
     return r;
 }
 DI float len_sq(V3 a) { return dot3(a, a); }
-DI float rsqrt_c(float x) { return 1.0f / __builtin_sqrtf(x); } // rsqrtf in IEEE form
-DI float length3(V3 a) { return 1.0f / rsqrt_c(len_sq(a)); }    // vec.hpp:398-409
+DI float rsqrt_c(float x) { return rcp_exact(__builtin_sqrtf(x)); } // rsqrtf in IEEE form
+DI float length3(V3 a) { return rcp_exact(rsqrt_c(len_sq(a))); }    // vec.hpp:398-409
 // vec::operator/=(T) (vec.hpp:739-769)
 DI V3 div_s(V3 a, float y) {
     if (y == 0.0f) return a;
-    float inv = 1.0f / y;
+    float inv = rcp_exact(y);
     return a * inv;
 }
 // vec::normalize (vec.hpp:411-422)
 DI V3 normalize3(V3 a) {
     float len = length3(a);
     if (len == 0.0f) return a;
-    float inv = 1.0f / len;
+    float inv = rcp_exact(len);
     return a * inv;
 }
 DI V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
@@ -83,9 +113,11 @@ DI V3 refract3(V3 d, V3 n, float eta) {
     V3 par = div_s(neg(n), rsqrt_c(__builtin_fabsf(1.0f - lsq)));
     return perp + par;
 }
+// Ray(origin, dir) keeps dir as given when it is shorter than 1e-4, else normalises (Ray.hpp:37-43).
+DI V3 ray_dir(V3 d) { return eps_equal(len_sq(d), 0.0f, kEpsSq) ? d : normalize3(d); }
 
 // ---------------------------------------------------------------- XORWOW (cuRAND)
-// State words {v0..v4, d}; next() is curand(), uniform() is curand_uniform()
+// State words {v0..v4, d}; rng_uniform() is curand_uniform()
 // (main.cu:177-178,324; AreaLight.hpp:342-343).
 struct Rng {
     uint32_t v0, v1, v2, v3, v4, d;
@@ -111,6 +143,7 @@ DI void rng_step(Rng& s) {
     s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
     s.d += 362437u;
 }
+// x * 2^-32 is exact, so the multiply-add below rounds once, fused or not.
 DI float rng_to_uniform(uint32_t x) { return (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f); }
 DI float rng_uniform(Rng& s) {
     rng_step(s);
@@ -172,18 +205,18 @@ DI void sincos_c(float a, float& s, float& c) {
 
 // ------------------------------------------------------------ intersection tests
 // Sphere::hit (Sphere.hpp:40-98): returns the accepted root in t.  dd = d.d.
-DI bool sphere_t(const DevGeom& g, V3 o, V3 d, float dd, float dist, float& t) {
-    V3 L = o - ld3(g.center);
+DI bool sphere_t(V3 center, float radius_sq, V3 o, V3 d, float dd, float dist, float& t) {
+    V3 L = o - center;
     float a = dd;
     float b = 2.0f * dot3(d, L);
-    float c = dot3(L, L) - g.radius_sq;
+    float c = dot3(L, L) - radius_sq;
     float discr = b * b - 4.0f * a * c;
     if (discr < 0.0f) return false;
     float t0, t1;
     if (eps_equal(discr, 0.0f, kEps)) {
         t0 = t1 = -0.5f * (b / a);
     } else {
-        float sq = 1.0f / rsqrt_c(discr);
+        float sq = rcp_exact(rsqrt_c(discr));
         float q = (b > 0.0f) ? -0.5f * (b + sq) : -0.5f * (b - sq);
         t0 = q / a;
         t1 = c / q;
@@ -202,14 +235,33 @@ DI bool sphere_t(const DevGeom& g, V3 o, V3 d, float dd, float dist, float& t) {
     return true;
 }
 
-// Bilinear-quad test shared by Quad::hit (Quad.hpp:196-295) and
-// AreaLight::_hittedLight (AreaLight.hpp:378-481).  p = ray origin relative to
-// corner 0.  LIGHT selects _hittedLight's 0.5f * (1/k2) (AreaLight.hpp:456).
-template <bool LIGHT, class Q>
-DI bool quad_tuv(const Q& g, V3 p, V3 d, float dist, float& t, float& u, float& v) {
-    V3 nor = ld3(g.nor);
-    float tt = -(dot3(p, nor) / dot3(d, nor));
+// Plane part of the quad test: t = -(p.nor / d.nor), rejected when t < 0 or
+// (dist > 0 and t > dist) (Quad.hpp:222-226).  `closest` is the caller's
+// best-so-far distance: a candidate with t > closest is discarded by
+// GeometryList::hit (GeometryList.hpp:28) whatever its (u,v), so it may be
+// dropped here as well.  The three quick tests decide from signs and a
+// multiplication when the quotient is certainly out of range (margin 1e-6
+// against the 6e-8 rounding of the quotient); everything else, including any
+// NaN or zero operand, goes through the exact division.
+DI bool quad_plane_t(V3 p, V3 d, V3 nor, float dist, float closest, float& t) {
+    float pn = dot3(p, nor), dn = dot3(d, nor);
+    float apn = __builtin_fabsf(pn), adn = __builtin_fabsf(dn);
+    bool same_sign = (pn > 0.0f && dn > 0.0f) || (pn < 0.0f && dn < 0.0f);
+    if (same_sign && apn > 1e-30f && adn < 1e6f) return false; // quotient > 1e-36 > 0  =>  t < 0
+    float lim = (dist > 0.0f && dist < closest) ? dist : closest;
+    float m = (adn * lim) * 1.000001f;
+    if (!same_sign && apn > m && m > 1e-30f && lim < 1e30f) return false; // t = |pn/dn| > lim
+    float tt = -(pn / dn);
     if (tt < 0.0f || (dist > 0.0f && tt > dist)) return false;
+    t = tt;
+    return true;
+}
+
+// Bilinear part of the quad test (Quad.hpp:228-295; AreaLight.hpp:406-480 with
+// LIGHT, whose only difference is 0.5f * (1/k2), AreaLight.hpp:456).
+// p = ray origin relative to corner 0, tt = accepted plane distance.
+template <bool LIGHT, class UVT>
+DI bool quad_uv(const UVT& g, V3 p, V3 d, float tt, float& u, float& v) {
     V3 pos = p + d * tt;
     float kpx = comp(pos, g.idu), kpy = comp(pos, g.idv);
     float kax = g.ka[0], kay = g.ka[1], kbx = g.kb[0], kby = g.kb[1], kgx = g.kg[0], kgy = g.kg[1];
@@ -223,42 +275,76 @@ DI bool quad_tuv(const Q& g, V3 p, V3 d, float dist, float& t, float& u, float& 
     } else {
         float w = k1 * k1 - 4.0f * k0 * k2;
         if (w < 0.0f) return false;
-        w = 1.0f / rsqrt_c(w);
-        float ik2 = LIGHT ? 0.5f * (1.0f / k2) : 1.0f / (2.0f * k2);
+        w = rcp_exact(rsqrt_c(w));
+        float ik2 = LIGHT ? 0.5f * rcp_exact(k2) : rcp_exact(2.0f * k2);
         vv = (-k1 - w) * ik2;
         if (vv < 0.0f || vv > 1.0f) vv = (-k1 + w) * ik2;
         uu = (kpx - kax * vv) / (kbx + kgx * vv);
     }
     if (min_std(uu, vv) < 0.0f || max_std(uu, vv) > 1.0f) return false;
-    t = tt;
     u = uu;
     v = vv;
     return true;
 }
 
+// Register copy of a DevGeomUV read through the constant address space.
+struct UVRec {
+    uint32_t idu, idv, linear;
+    float nor_id, ka[2], kb[2], kg[2], k2;
+};
+DI UVRec load_uv(const DevGeomUV CRT_CONST* q) {
+    UVRec r;
+    r.idu = q->idu;
+    r.idv = q->idv;
+    r.linear = q->linear;
+    r.nor_id = q->nor_id;
+    r.ka[0] = q->ka[0];
+    r.ka[1] = q->ka[1];
+    r.kb[0] = q->kb[0];
+    r.kb[1] = q->kb[1];
+    r.kg[0] = q->kg[0];
+    r.kg[1] = q->kg[1];
+    r.k2 = q->k2;
+    return r;
+}
+
 struct Hit {
     int idx; // -1: nothing hit
+    uint32_t mat_type;
     float t, u, v;
 };
 
 // GeometryList::hit (GeometryList.hpp:22-35): closest hit, ties and unordered
-// distances go to the later primitive.
-DI Hit closest_hit(const DevScene* __restrict__ sc, V3 o, V3 d, float dist) {
+// distances go to the later primitive.  The loop index is wave-uniform, so each
+// primitive costs one 8-dword scalar load.
+DI Hit closest_hit(ScenePtr sc, V3 o, V3 d, float dist) {
     Hit h;
     h.idx = -1;
+    h.mat_type = 0;
     h.t = kFltMax;
     h.u = 0.0f;
     h.v = 0.0f;
     const float dd = dot3(d, d);
     const uint32_t n = sc->n_geom;
     for (uint32_t i = 0; i < n; ++i) {
-        const DevGeom& g = sc->geom[i];
-        float t, u = 0.0f, v = 0.0f;
+        const DevGeomHot CRT_CONST* g = &sc->hot[i];
+        const uint32_t kind = g->kind, mat = g->mat_type;
+        const V3 go = ld3c(g->o), gn = ld3c(g->n);
+        float t = 0.0f, u = 0.0f, v = 0.0f;
         bool hit;
-        if (g.kind == CRT_GEOM_SPHERE) hit = sphere_t(g, o, d, dd, dist, t);
-        else hit = quad_tuv<false>(g, o - ld3(g.v0), d, dist, t, u, v);
+        if (kind == CRT_GEOM_SPHERE) {
+            hit = sphere_t(go, gn.x, o, d, dd, dist, t);
+        } else {
+            V3 p = o - go;
+            hit = quad_plane_t(p, d, gn, dist, h.t, t);
+            if (hit) {
+                UVRec q = load_uv(&sc->uv[i]);
+                hit = quad_uv<false>(q, p, d, t, u, v);
+            }
+        }
         if (hit && !(t > h.t)) {
             h.idx = (int)i;
+            h.mat_type = mat;
             h.t = t;
             h.u = u;
             h.v = v;
@@ -268,53 +354,51 @@ DI Hit closest_hit(const DevScene* __restrict__ sc, V3 o, V3 d, float dist) {
 }
 
 // Hit point and shading normal of an accepted hit (Sphere.hpp:102-107, Quad.hpp:299-325).
-DI void hit_point_normal(const DevScene* __restrict__ sc, const Hit& h, V3 o, V3 d, V3& P, V3& N) {
-    const DevGeom& g = sc->geom[h.idx];
+DI void hit_point_normal(ScenePtr sc, const Hit& h, V3 o, V3 d, V3& P, V3& N) {
     P = o + d * h.t;
-    if (g.kind == CRT_GEOM_SPHERE) {
-        N = normalize3(P - ld3(g.center));
+    if (sc->hot[h.idx].kind == CRT_GEOM_SPHERE) {
+        N = normalize3(P - ld3c(sc->hot[h.idx].o));
     } else {
+        const DevGeomShade CRT_CONST* g = &sc->shade[h.idx];
         float u = h.u, v = h.v;
         float l0 = (1 - u) * (1 - v);
         float l1 = u * (1 - v);
         float l2 = u * v;
         float l3 = (1 - u) * v;
-        N = V3{l0 * g.n[0][0] + l1 * g.n[1][0] + l2 * g.n[2][0] + l3 * g.n[3][0],
-               l0 * g.n[0][1] + l1 * g.n[1][1] + l2 * g.n[2][1] + l3 * g.n[3][1],
-               l0 * g.n[0][2] + l1 * g.n[1][2] + l2 * g.n[2][2] + l3 * g.n[3][2]};
+        N = V3{l0 * g->n[0][0] + l1 * g->n[1][0] + l2 * g->n[2][0] + l3 * g->n[3][0],
+               l0 * g->n[0][1] + l1 * g->n[1][1] + l2 * g->n[2][1] + l3 * g->n[3][1],
+               l0 * g->n[0][2] + l1 * g->n[1][2] + l2 * g->n[2][2] + l3 * g->n[3][2]};
     }
 }
 
-// Ray(origin, dir) keeps dir as given when it is shorter than 1e-4, else normalises (Ray.hpp:37-43).
-DI V3 ray_dir(V3 d) { return eps_equal(len_sq(d), 0.0f, kEpsSq) ? d : normalize3(d); }
-
 // Glass on the way to the light: the part of Light::_isCovered (Light.hpp:47-80)
 // entered when the closest hit is Refractive.  Returns "covered".
-DI bool covered_through_glass(const DevScene* __restrict__ sc, const DevLight& L, V3 o, V3 d, Hit h) {
+DI bool covered_through_glass(ScenePtr sc, const DevLight CRT_CONST* L, V3 o, V3 d, Hit h) {
     // The do/while of the reference runs at most `iterations` = 10 passes; pass 0 found h.
     for (unsigned i = 0;;) {
-        const DevGeom& g = sc->geom[h.idx];
         V3 P, N;
         hit_point_normal(sc, h, o, d, P, N);
         bool front_face = dot3(d, N) < 0.0f;
         V3 norm = front_face ? N : neg(N);
-        float ratio = g.refract_index / 1.0f;
-        if (front_face) ratio = 1.0f / ratio;
+        float ratio = sc->shade[h.idx].refract_index / 1.0f;
+        if (front_face) ratio = rcp_exact(ratio);
         V3 rd = normalize3(d);
         float cos_theta = __builtin_fminf(dot3(neg(rd), norm), 1.0f);
-        float sin_theta = 1.0f / rsqrt_c(1.0f - cos_theta * cos_theta);
+        float sin_theta = rcp_exact(rsqrt_c(1.0f - cos_theta * cos_theta));
         // reflectance(...) > 1.0f (Light.hpp:61) cannot hold for cos_theta in [0,1]; only the TIR test remains.
         if (ratio * sin_theta > 1.0f) return true;
         V3 dir = refract3(rd, norm, ratio);
         V3 ro = P + dir * 0.01f;
         V3 rdir = ray_dir(dir);
         if (!front_face) {
-            if (L.kind == CRT_LIGHT_AREA) {
+            if (L->kind == CRT_LIGHT_AREA) { // AreaLight::_hittedLight (AreaLight.hpp:378-481)
                 float t, u, v;
-                V3 p = (ro - ld3(L.p[0])) - ld3(L.pos);
-                return !quad_tuv<true>(L, p, rdir, 0.0f, t, u, v);
+                V3 p = (ro - ld3c(L->p0)) - ld3c(L->pos);
+                if (!quad_plane_t(p, rdir, ld3c(L->nor), 0.0f, kFltMax, t)) return true;
+                UVRec q = load_uv(&L->uv);
+                return !quad_uv<true>(q, p, rdir, t, u, v);
             } else { // Ray::isPointOnRay (Ray.hpp:80-105) with distance 0
-                V3 w = ld3(L.pos) - ro;
+                V3 w = ld3c(L->pos) - ro;
                 V3 cr = cross3(rdir, w);
                 if (len_sq(cr) >= kEpsSq) return true;
                 return !(dot3(w, rdir) >= 0.0f);
@@ -326,16 +410,8 @@ DI bool covered_through_glass(const DevScene* __restrict__ sc, const DevLight& L
         if (!(i < 10u)) return true; // loop ends with hit.isHit still set
         h = closest_hit(sc, o, d, 0.0f);
         if (h.idx < 0) return false;
-        if (sc->geom[h.idx].mat_type != CRT_MAT_REFRACTIVE) return true;
+        if (h.mat_type != CRT_MAT_REFRACTIVE) return true;
     }
-}
-
-// Light::_isCovered (Light.hpp:35-86) for a shadow ray.
-DI bool is_covered(const DevScene* __restrict__ sc, const DevLight& L, V3 o, V3 d, float dist) {
-    Hit h = closest_hit(sc, o, d, dist);
-    if (h.idx < 0) return false;
-    if (sc->geom[h.idx].mat_type != CRT_MAT_REFRACTIVE) return true;
-    return covered_through_glass(sc, L, o, d, h);
 }
 
 // ------------------------------------------------------------------ LTC shading
@@ -386,6 +462,11 @@ DI void surface_frame(V3 n, V3& Nx, V3& Nz) {
     if (__builtin_fabsf(n.x) > __builtin_fabsf(n.y)) Nx = mk3(n.z, 0.0f, -n.x) * rsqrt_c(n.x * n.x + n.z * n.z);
     else Nx = mk3(0.0f, -n.z, n.y) * rsqrt_c(n.y * n.y + n.z * n.z);
     Nz = cross3(n, Nx);
+}
+
+// ---------------------------------------------------------------- wave helpers
+DI uint32_t lane_rank(uint64_t mask) { // number of set bits below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
 } // namespace crt

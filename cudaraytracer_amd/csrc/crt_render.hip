@@ -2,23 +2,33 @@
 // (render -> aa_color -> color -> GeometryList::hit / AreaLight::calculateColor,
 // main.cu:110-347).
 //
-// Execution shape.  One lane = one pixel; a wave = an 8x8 pixel tile; one wave
-// per workgroup, so the dispatcher balances uneven tiles over the 1024 SIMDs.
-// The reference's two explicit stacks (RayState[128] in color(), AA_Task[256] in
-// aa_color()) are replaced by O(depth) per-lane state:
-//   * a pending mirror/glass ray (a Reflect/Refractive hit pushes one ray that is
-//     popped at once),
+// Execution shape.  A workgroup is one wave.  The grid is persistent: every wave
+// pulls work units (8x8 pixel tiles) from a global counter, and every *lane*
+// pulls the next pixel of its wave's current unit as soon as it has finished
+// its previous pixel, so lanes stay busy although pixels cost very different
+// amounts (an escaping ray costs nothing, a diffuse hit costs shadowSamples
+// shadow rays and two LTC integrals, times ind_rays^depth).
+//
+// The reference's two explicit stacks (RayState[128] in color(), AA_Task[256]
+// in aa_color()) are replaced by O(depth) per-lane state:
+//   * a pending mirror/glass ray (a Reflect/Refractive hit pushes one ray that
+//     is popped at once),
 //   * one Frame per nested global-illumination level.  A diffuse hit at depth>0
 //     draws its ind_rays (r1,r2) pairs exactly as the reference does, but keeps
-//     only the generator state reached after the last *accepted* child; children
-//     are popped last-to-first by stepping that state backwards (XORWOW's
-//     xorshift is a bijection), so no child is ever stored.  The reference's
-//     128-entry truncation is a function of how many entries are on its stack,
-//     which here is the sum of the frames' remaining-children counters.
+//     only the generator state reached after the last *accepted* child;
+//     children are popped last-to-first by stepping that state backwards
+//     (XORWOW's xorshift is a bijection), so no child is ever stored.  The
+//     reference's 128-entry truncation is a function of how many entries are on
+//     its stack, which here is the sum of the frames' remaining-children counters.
 //   * a 10-entry adaptive-AA task list (aa_iter <= 4 bounds it: 1 + 3*3).
-// Each lane alternates between a cheap phase that walks rays until it owns a
-// diffuse hit to shade, and the expensive shading phase (shadowSamples shadow
-// rays + two LTC polygon integrals) that all lanes of the wave enter together.
+//
+// Each wave alternates between phase A, in which lanes step rays (camera rays,
+// GI children, mirror/glass bounces) until each owns a diffuse hit, and phase B,
+// in which all lanes shade their hit together: shadowSamples shadow rays against
+// a scene held in scalar registers, then two LTC polygon integrals.  Shadow rays
+// that meet glass first need the refraction walk of Light::_isCovered; that rare,
+// long path is not taken in place (it would idle the other 63 lanes) but queued
+// in LDS and drained 64 entries at a time with every lane busy.
 #include <hip/hip_runtime.h>
 
 #include "crt_device.hpp"
@@ -28,13 +38,15 @@ namespace crt {
 
 namespace {
 
+constexpr uint32_t kQueueCap = 128; // >= 63 left over + 64 new entries per sample round
+
 struct Frame {
-    float P[3];   // hit point the children leave from
-    float N[3];   // its shading normal
-    float att[4]; // attenuation of the expanding ray (RayState::attenuation)
+    float P[3];      // hit point the children leave from
+    float N[3];      // its shading normal
+    float att[4];    // attenuation of the expanding ray (RayState::attenuation)
     uint32_t rng[6]; // generator state right after the draws of child `remaining-1`
     uint32_t geom;   // primitive hit (for Material::diffuse)
-    uint32_t remaining; // children still on the reference's stack
+    uint32_t remaining;   // children still on the reference's stack
     uint32_t child_depth; // global_depth of the children
 };
 
@@ -43,35 +55,28 @@ struct AATask {
     uint32_t level; // AA_Task::sample
 };
 
-// Which pixel a lane renders and where its result goes.
+// Which pixel slot `idx` (0..63) of work unit `unit` is, and where its result goes.
 struct PixelMap {
     bool valid;
-    uint32_t i, j;    // pixel coordinates
-    size_t out_index; // RGBA slot in the output buffer (in pixels)
-    bool store;       // write even when !valid (shard padding)
+    uint32_t i, j;     // pixel coordinates
+    uint32_t out_index; // RGBA slot in the output buffer (in pixels)
 };
 
-DI PixelMap map_pixel(const RenderArgs& a, uint32_t wave, uint32_t lane) {
+DI PixelMap map_pixel(const RenderArgs& a, uint32_t unit, uint32_t idx) {
     PixelMap m;
     m.valid = false;
-    m.store = false;
     m.i = m.j = 0;
     m.out_index = 0;
     if (a.mode == MODE_FULL || a.mode == MODE_SHARD) {
-        uint32_t tile = (a.mode == MODE_SHARD) ? wave * a.world + a.rank : wave;
+        uint32_t tile = (a.mode == MODE_SHARD) ? unit * a.world + a.rank : unit;
         uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        m.i = tx * 8u + (lane & 7u);
-        m.j = ty * 8u + (lane >> 3);
+        m.i = tx * 8u + (idx & 7u);
+        m.j = ty * 8u + (idx >> 3);
         m.valid = (m.i < a.nx) && (m.j < a.ny) && (tile < a.tiles_x * a.tiles_y);
-        if (a.mode == MODE_SHARD) {
-            m.out_index = (size_t)wave * 64u + lane;
-            m.store = true;
-        } else {
-            m.out_index = (size_t)m.j * a.nx + m.i;
-        }
+        m.out_index = (a.mode == MODE_SHARD) ? unit * 64u + idx : m.j * a.nx + m.i;
     } else { // MODE_PARTIAL: window of reference blocks (render_partial, main.cu:349-353)
         uint32_t per_block = a.tx * a.ty;
-        uint32_t p = wave * 64u + lane;
+        uint32_t p = unit * 64u + idx;
         uint32_t b = p / per_block, q = p - b * per_block;
         if (b < a.win_bx * a.win_by) {
             uint32_t by = b / a.win_bx, bx = b - by * a.win_bx;
@@ -79,53 +84,25 @@ DI PixelMap map_pixel(const RenderArgs& a, uint32_t wave, uint32_t lane) {
             m.i = lx + ((a.start_bx + bx) % a.blocks_x) * a.tx;
             m.j = ly + ((a.start_by + by) % a.blocks_y) * a.ty;
             m.valid = (m.i < a.nx) && (m.j < a.ny);
-            m.out_index = (size_t)m.j * a.nx + m.i;
+            m.out_index = m.j * a.nx + m.i;
         }
     }
     return m;
 }
 
-// AreaLight::calculateColor (AreaLight.hpp:571-650) incl. _calculateVisibility (:484-529).
-DI V4 area_light_color(const DevScene* __restrict__ sc, const float* __restrict__ ltc, const DevLight& L,
-                       const DevGeom& g, V3 P, V3 N, V3 view, Rng& rng) {
-    V3 lcol = ld3(L.color);
-    V3 ambient = mk3(g.ambient[0], g.ambient[1], g.ambient[2]) * lcol;
-    if (!L.initialized) return V4{ambient.x, ambient.y, ambient.z, 1.0f};
-
-    // ---- soft shadow: shadow_samples rays to uniformly drawn points of the quad
-    const uint32_t S = L.shadow_samples;
-    uint32_t shadowed = 0;
-    const V3 lpos = ld3(L.pos);
-    for (uint32_t s = 0; s < S; ++s) {
-        float u = rng_uniform(rng);
-        float v = rng_uniform(rng);
-        V3 sample; // _randomPoint (AreaLight.hpp:340-375)
-        if (u + v < 1.0f) {
-            sample = ((ld3(L.p[0]) + ld3(L.e01) * u) + ld3(L.e03) * v) + lpos;
-        } else {
-            u = 1.0f - u;
-            v = 1.0f - v;
-            sample = ((ld3(L.p[2]) + ld3(L.e23) * u) + ld3(L.e21) * v) + lpos;
-        }
-        V3 dir = sample - P;
-        float dist = length3(dir);
-        if (!eps_equal(dist, 0.0f, kEps)) dir = normalize3(dir);
-        V3 o = P + dir * 0.01f;
-        V3 d = ray_dir(dir);                  // Ray ctor normalises once more (Ray.hpp:45-52)
-        float maxd = max_std(0.0f, dist);     // Ray::setDistance
-        if (is_covered(sc, L, o, d, maxd)) ++shadowed;
-    }
-    float visibility = 1.0f - ((float)shadowed / (float)S);
-
-    // ---- LTC lookups (AreaLight.hpp:604-635)
+// LTC part of AreaLight::calculateColor (AreaLight.hpp:595-649) once the visibility is known.
+DI V4 area_light_shade(const float* __restrict__ ltc, const DevLight CRT_CONST* L,
+                       const DevGeomShade CRT_CONST* g, V3 P, V3 N, V3 view, float visibility) {
+    V3 lcol = ld3c(L->color);
+    V3 ambient = mk3(g->ambient[0], g->ambient[1], g->ambient[2]) * lcol;
     const float* ltc1 = ltc;
     const float* ltc2 = ltc + 64 * 64 * 4;
-    V3 dcol = mk3(g.diffuse[0], g.diffuse[1], g.diffuse[2]);
-    V3 scol = mk3(g.specular[0], g.specular[1], g.specular[2]);
+    V3 dcol = mk3(g->diffuse[0], g->diffuse[1], g->diffuse[2]);
+    V3 scol = mk3(g->specular[0], g->specular[1], g->specular[2]);
     float ndotv = saturate_c(dot3(N, view));
     const float LUT_SCALE = 63.0f / 64.0f, LUT_BIAS = 0.5f / 64.0f;
-    float uvy = (1.0f / rsqrt_c(1.0f - ndotv)) * LUT_SCALE + LUT_BIAS;
-    uint32_t ty = ltc_texel(uvy), tx = g.ltc_col;
+    float uvy = rcp_exact(rsqrt_c(1.0f - ndotv)) * LUT_SCALE + LUT_BIAS;
+    uint32_t ty = ltc_texel(uvy), tx = g->ltc_col;
     V4 t1 = V4{0, 0, 0, 0}, t2 = V4{0, 0, 0, 0};
     if (tx < 64u && ty < 64u) {
         const float4 a = *reinterpret_cast<const float4*>(ltc1 + (ty * 64u + tx) * 4u);
@@ -133,14 +110,13 @@ DI V4 area_light_color(const DevScene* __restrict__ sc, const float* __restrict_
         t1 = V4{a.x, a.y, a.z, a.w};
         t2 = V4{b.x, b.y, b.z, b.w};
     }
-
-    // ---- _evaluateLTC twice (AreaLight.hpp:216-297): identity, then Minv
+    // _evaluateLTC twice (AreaLight.hpp:216-297): identity, then Minv
     V3 T1 = view - N * dot3(view, N);
     if (!eps_equal(len_sq(T1), 0.0f, kEpsSq)) T1 = normalize3(T1);
     V3 T2 = cross3(N, T1);
-    V3 w0 = ld3(L.pts[0]) - P, w1 = ld3(L.pts[1]) - P, w2 = ld3(L.pts[2]) - P, w3 = ld3(L.pts[3]) - P;
-    bool behind = dot3(w0, ld3(L.light_normal)) < 0.0f;
-    bool two_sided = L.two_sided != 0u;
+    V3 w0 = ld3c(L->pts[0]) - P, w1 = ld3c(L->pts[1]) - P, w2 = ld3c(L->pts[2]) - P, w3 = ld3c(L->pts[3]) - P;
+    bool behind = dot3(w0, ld3c(L->light_normal)) < 0.0f;
+    bool two_sided = L->two_sided != 0u;
     // identity * transpose(T1,T2,N): rows T1, T2, N
     float dsum = ltc_polygon(ltc2, mk3(dot3(T1, w0), dot3(T2, w0), dot3(N, w0)),
                              mk3(dot3(T1, w1), dot3(T2, w1), dot3(N, w1)),
@@ -158,31 +134,32 @@ DI V4 area_light_color(const DevScene* __restrict__ sc, const float* __restrict_
                              mk3(dot3(r0, w1), dot3(r1, w1), dot3(r2, w1)),
                              mk3(dot3(r0, w2), dot3(r1, w2), dot3(r2, w2)),
                              mk3(dot3(r0, w3), dot3(r1, w3), dot3(r2, w3)), behind, two_sided);
-
     V3 diffuse = (lcol * mk3(dsum, dsum, dsum)) * dcol;
     V3 spec = mk3(ssum, ssum, ssum) * (scol * t2.x + (mk3(1.0f, 1.0f, 1.0f) - scol) * t2.y);
     V3 specular = lcol * spec;
-    V3 result = ambient + ((diffuse + specular) * L.intensity) * visibility;
+    V3 result = ambient + ((diffuse + specular) * L->intensity) * visibility;
     return V4{result.x, result.y, result.z, 1.0f};
 }
 
 // Light::calculateColor, point light with Blinn-Phong (Light.hpp:92-111,119-182).
-DI V4 point_light_color(const DevScene* __restrict__ sc, const DevLight& L, const DevGeom& g, V3 P, V3 N, V3 view) {
-    V3 lcol = ld3(L.color);
-    V3 ambient = mk3(g.ambient[0], g.ambient[1], g.ambient[2]) * lcol;
-    V3 lpos = ld3(L.pos);
+DI V4 point_light_color(ScenePtr sc, const DevLight CRT_CONST* L, const DevGeomShade CRT_CONST* g, V3 P, V3 N, V3 view) {
+    V3 lcol = ld3c(L->color);
+    V3 ambient = mk3(g->ambient[0], g->ambient[1], g->ambient[2]) * lcol;
+    V3 lpos = ld3c(L->pos);
     V3 rayDir = lpos - P;
     float lightDist = length3(rayDir);
     if (!eps_equal(lightDist, 0.0f, kEps)) rayDir = normalize3(rayDir);
-    if (is_covered(sc, L, P + rayDir * 0.01f, ray_dir(rayDir), max_std(0.0f, lightDist)))
-        return V4{ambient.x, ambient.y, ambient.z, 1.0f};
+    V3 so = P + rayDir * 0.01f, sd = ray_dir(rayDir);
+    Hit h = closest_hit(sc, so, sd, max_std(0.0f, lightDist));
+    bool covered = h.idx >= 0 && (h.mat_type != CRT_MAT_REFRACTIVE || covered_through_glass(sc, L, so, sd, h));
+    if (covered) return V4{ambient.x, ambient.y, ambient.z, 1.0f};
     V3 lightDir = lpos - P;
     if (!eps_equal(len_sq(lightDir), 0.0f, kEpsSq)) lightDir = normalize3(lightDir);
     float diff = max_std(dot3(N, lightDir), 0.0f);
-    V3 diffuse = (lcol * (mk3(g.diffuse[0], g.diffuse[1], g.diffuse[2]) * diff)) * L.intensity;
+    V3 diffuse = (lcol * (mk3(g->diffuse[0], g->diffuse[1], g->diffuse[2]) * diff)) * L->intensity;
     V3 halfway = normalize3(lightDir + view);
-    float spec = __builtin_powf(max_std(dot3(N, halfway), 0.0f), g.shininess);
-    V3 specular = (lcol * (mk3(g.specular[0], g.specular[1], g.specular[2]) * spec)) * L.intensity;
+    float spec = __builtin_powf(max_std(dot3(N, halfway), 0.0f), g->shininess);
+    V3 specular = (lcol * (mk3(g->specular[0], g->specular[1], g->specular[2]) * spec)) * L->intensity;
     V3 result = (ambient + diffuse) + specular;
     return V4{result.x, result.y, result.z, 1.0f};
 }
@@ -203,55 +180,50 @@ __global__ void __launch_bounds__(64) random_init_kernel(uint32_t npix, uint64_t
 }
 
 __global__ void __launch_bounds__(64) render_kernel(RenderArgs a) {
-    const DevScene* __restrict__ sc = a.scene;
+    ScenePtr sc = (ScenePtr)a.scene;
     const float* __restrict__ ltc = a.ltc;
     const uint32_t lane = threadIdx.x;
-    const PixelMap pm = map_pixel(a, blockIdx.x, lane);
     float4* __restrict__ out = reinterpret_cast<float4*>(a.out);
-    if (!pm.valid) {
-        if (pm.store) out[pm.out_index] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    const size_t npix = (size_t)a.nx * a.ny;
-    const size_t pix = (size_t)pm.j * a.nx + pm.i;
-    Rng rng;
-    rng.v0 = a.rng[0 * npix + pix];
-    rng.v1 = a.rng[1 * npix + pix];
-    rng.v2 = a.rng[2 * npix + pix];
-    rng.v3 = a.rng[3 * npix + pix];
-    rng.v4 = a.rng[4 * npix + pix];
-    rng.d = a.rng[5 * npix + pix];
+    const uint32_t npix = a.nx * a.ny;
 
-    // get_world_coordinates (main.cu:306-314) and pixel_size (main.cu:337)
+    // deferred glass-shadow work: ray, first hit and the lane that owns the sample
+    __shared__ float q_f[9][kQueueCap];
+    __shared__ uint32_t q_meta[kQueueCap];
+    __shared__ uint32_t s_shadow[64];
+
+    // get_world_coordinates (main.cu:306-314) and pixel_size (main.cu:337): image-wide constants
     const float height_world = 2.0f;
     const float width_world = height_world * ((float)a.nx / (float)a.ny);
-    float x_world, y_world;
-    {
-        float denom = (float)a.nx - 0.0f; // remap<float,true> (math_functions.hpp:31-45)
-        float es = -width_world * 0.5f, ee = width_world * 0.5f;
-        x_world = (denom == 0.0f) ? (float)pm.i : es + ((ee - es) / denom) * ((float)pm.i - 0.0f);
-        float denomy = (float)a.ny - 0.0f;
-        y_world = (denomy == 0.0f) ? (float)pm.j : 1.0f + ((-1.0f - 1.0f) / denomy) * ((float)pm.j - 0.0f);
-    }
     const float pix_w = width_world / (float)a.nx, pix_h = height_world / (float)a.ny;
 
     // Camera::getRay constants (Camera.hpp:97-98,133-134)
-    const DevCamera& cam = sc->cam;
-    const V3 cam_pos = ld3(cam.pos), cam_front = ld3(cam.front), cam_right = ld3(cam.right), cam_up = ld3(cam.up);
-    const V3 eye = cam_pos - cam_front * (width_world * 0.5f * cam.one_over_tan);
-    float ortho = 0.0f;
+    const V3 cam_pos = ld3c(sc->cam.pos), cam_front = ld3c(sc->cam.front), cam_right = ld3c(sc->cam.right),
+             cam_up = ld3c(sc->cam.up);
+    const V3 eye = cam_pos - cam_front * (width_world * 0.5f * sc->cam.one_over_tan);
+    const uint32_t cam_type = sc->cam.type;
+    float ortho;
     {
         float aspect = height_world / width_world;
-        ortho = cam.ortho_scale * (aspect > 1.0f ? aspect : 1.0f);
+        ortho = sc->cam.ortho_scale * (aspect > 1.0f ? aspect : 1.0f);
     }
-
     const uint32_t aa_iter = a.aa_iter > 4u ? 4u : a.aa_iter; // main.cu:233
     const float inv_ind = 1.0f / (float)a.ind_rays;            // main.cu:182
 
-    // ---- adaptive-AA task list (aa_color, main.cu:230-304)
+    // ---- wave-uniform work pool
+    uint32_t unit = blockIdx.x;
+    bool unit_valid = unit < a.n_units;
+    bool exhausted = !unit_valid;
+    uint32_t next = 0;
+
+    // ---- per-lane pixel state
+    bool pixel_active = false, lane_dead = false;
+    uint32_t pix = 0, out_index = 0;
+    Rng rng = {0, 0, 0, 0, 0, 0};
+    uint32_t cnt_shade = 0, cnt_expand = 0;
+
+    // adaptive-AA task list (aa_color, main.cu:230-304)
     AATask aa_stack[10];
     uint32_t aa_top = 0;
-    aa_stack[aa_top++] = AATask{x_world, y_world, aa_iter};
     V4 acc = V4{0, 0, 0, 0};
     bool task_active = false;
     float t_cx = 0, t_cy = 0;
@@ -259,258 +231,445 @@ __global__ void __launch_bounds__(64) render_kernel(RenderArgs a) {
     bool t_all_equal = true;
     V4 t_c0 = V4{0, 0, 0, 0};
 
-    // ---- color() state (main.cu:110-227)
+    // color() state (main.cu:110-227)
     Frame frames[CRT_MAX_GL_ITER];
     uint32_t nframes = 0;
     uint32_t on_stack = 0; // entries the reference's stack would hold
     bool color_active = false;
     V4 final_c = V4{0, 0, 0, 0};
     V3 ray_d = mk3(0.0f, 0.0f, -1.0f); // Ray::_direction survives a degenerate setDirection (Ray.hpp:62-69)
-    // pending ray (popped next)
-    bool cur_valid = false;
+    bool cur_valid = false;            // pending ray (popped next)
     V3 cur_o = mk3(0, 0, 0), cur_d = mk3(0, 0, 0);
     V4 cur_att = V4{1, 1, 1, 1};
     uint32_t cur_ref = 0, cur_depth = 0;
 
-    // node to shade
+    // diffuse hit waiting to be shaded
+    bool have_node = false;
     V3 n_P = mk3(0, 0, 0), n_N = mk3(0, 0, 0), n_view = mk3(0, 0, 0);
     V4 n_att = V4{0, 0, 0, 0};
     uint32_t n_geom = 0, n_depth = 0;
-    uint32_t cnt_shade = 0, cnt_expand = 0;
 
     for (;;) {
-        // ================= phase A: walk rays until this lane owns a diffuse hit
-        bool have_node = false;
-        bool done = false;
-        while (!have_node) {
-            if (!color_active) {
-                if (!task_active) {
-                    if (aa_top == 0) {
-                        done = true;
-                        break;
-                    }
-                    AATask t = aa_stack[--aa_top];
-                    t_cx = t.cx;
-                    t_cy = t.cy;
-                    t_level = t.level;
-                    t_corner = 0;
-                    t_all_equal = true;
-                    task_active = true;
-                }
-                // size of this task's box: pixel size halved (aa_iter - level) times (main.cu:251,297)
-                float sx = pix_w, sy = pix_h;
-                for (uint32_t k = t_level; k < aa_iter; ++k) {
-                    sx = sx * 0.5f;
-                    sy = sy * 0.5f;
-                }
-                float hx = sx * 0.5f, hy = sy * 0.5f;
-                float ox = (t_corner & 1u) ? 1.0f : -1.0f, oy = (t_corner & 2u) ? 1.0f : -1.0f;
-                float rx, ry;
-                if (t_level == 0u) {
-                    rx = t_cx;
-                    ry = t_cy;
-                } else if (t_level == 1u) {
-                    rx = t_cx + ox * hx * 0.5f;
-                    ry = t_cy + oy * hy * 0.5f;
-                } else {
-                    rx = t_cx + ox * hx;
-                    ry = t_cy + oy * hy;
-                }
-                // Camera::getRay (Camera.hpp:86-144)
-                V3 ro, rd;
-                if (cam.type == CRT_CAM_ORTHOGRAPHIC) {
-                    ro = ((cam_right * rx) * ortho + (cam_up * ry) * ortho) + cam_pos;
-                    rd = ray_dir(cam_front);
-                } else {
-                    ro = (cam_right * rx + cam_up * ry) + cam_pos;
-                    rd = ray_dir(ro - eye);
-                }
-                cur_o = ro;
-                cur_d = rd;
-                cur_att = V4{1.0f, 1.0f, 1.0f, 1.0f};
-                cur_ref = a.ref_iter;
-                cur_depth = a.gl_iter;
-                cur_valid = true;
-                color_active = true;
-                final_c = V4{0, 0, 0, 0};
-                ray_d = mk3(0.0f, 0.0f, -1.0f);
-                nframes = 0;
-                on_stack = 0;
-            }
-            if (!cur_valid) {
-                if (nframes == 0) {
-                    // color() returned: hand the colour to the AA task (main.cu:254-300)
-                    color_active = false;
-                    float mult = 1.0f / (float)(1u << (2u * (aa_iter - t_level)));
-                    if (t_level == 0u) {
-                        acc = acc + final_c * mult;
-                        task_active = false;
-                    } else if (t_level == 1u) {
-                        acc = acc + (final_c * mult) * 0.25f;
-                        if (++t_corner == 4u) task_active = false;
-                    } else {
-                        if (t_corner == 0u) t_c0 = final_c;
-                        else if (t_all_equal && !equal4(final_c, t_c0)) t_all_equal = false;
-                        if (++t_corner == 4u) {
+        // ===================== phase A: step rays until every live lane owns a diffuse hit
+        for (;;) {
+            // ---- (1) hand pixels to lanes that have none
+            for (;;) {
+                const bool want = !pixel_active && !lane_dead;
+                const uint64_t m = __ballot(want);
+                if (m == 0) break;
+                if (unit_valid && next < 64u) {
+                    const uint32_t idx = next + lane_rank(m);
+                    next += (uint32_t)__popcll(m);
+                    if (want && idx < 64u) {
+                        const PixelMap pm = map_pixel(a, unit, idx);
+                        if (pm.valid) {
+                            pixel_active = true;
+                            pix = pm.j * a.nx + pm.i;
+                            out_index = pm.out_index;
+                            rng.v0 = a.rng[0 * (size_t)npix + pix];
+                            rng.v1 = a.rng[1 * (size_t)npix + pix];
+                            rng.v2 = a.rng[2 * (size_t)npix + pix];
+                            rng.v3 = a.rng[3 * (size_t)npix + pix];
+                            rng.v4 = a.rng[4 * (size_t)npix + pix];
+                            rng.d = a.rng[5 * (size_t)npix + pix];
+                            // remap<float,true> (math_functions.hpp:31-45)
+                            float denom = (float)a.nx - 0.0f;
+                            float es = -width_world * 0.5f, ee = width_world * 0.5f;
+                            float x_world = (denom == 0.0f) ? (float)pm.i : es + ((ee - es) / denom) * ((float)pm.i - 0.0f);
+                            float denomy = (float)a.ny - 0.0f;
+                            float y_world = (denomy == 0.0f) ? (float)pm.j
+                                                             : 1.0f + ((-1.0f - 1.0f) / denomy) * ((float)pm.j - 0.0f);
+                            aa_top = 0;
+                            aa_stack[aa_top++] = AATask{x_world, y_world, aa_iter};
+                            acc = V4{0, 0, 0, 0};
                             task_active = false;
-                            if (t_all_equal) {
-                                acc = acc + t_c0 * mult;
+                            color_active = false;
+                            cur_valid = false;
+                            nframes = 0;
+                            cnt_shade = 0;
+                            cnt_expand = 0;
+                        }
+                    }
+                } else if (!exhausted) {
+                    uint32_t u = 0;
+                    if (lane == 0) u = gridDim.x + atomicAdd(a.unit_counter, 1u);
+                    u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+                    if (u < a.n_units) {
+                        unit = u;
+                        next = 0;
+                        unit_valid = true;
+                    } else {
+                        exhausted = true;
+                        unit_valid = false;
+                    }
+                } else {
+                    if (want) lane_dead = true;
+                }
+            }
+
+            // ---- (2) one ray step for every lane that still looks for a diffuse hit
+            const bool need = pixel_active && !have_node;
+            if (!__any(need)) break;
+            if (need) {
+                if (!cur_valid) {
+                    if (!color_active) {
+                        // aa_color: next camera ray of the current task, or finish the pixel
+                        if (!task_active && aa_top == 0) {
+                            // render() epilogue (main.cu:339-346)
+                            out[out_index] = make_float4(saturate_c(acc.x), saturate_c(acc.y), saturate_c(acc.z),
+                                                         saturate_c(acc.w));
+                            a.rng[0 * (size_t)npix + pix] = rng.v0;
+                            a.rng[1 * (size_t)npix + pix] = rng.v1;
+                            a.rng[2 * (size_t)npix + pix] = rng.v2;
+                            a.rng[3 * (size_t)npix + pix] = rng.v3;
+                            a.rng[4 * (size_t)npix + pix] = rng.v4;
+                            a.rng[5 * (size_t)npix + pix] = rng.d;
+                            a.counters[pix] += cnt_shade;
+                            a.counters[npix + pix] += cnt_expand;
+                            pixel_active = false;
+                        } else {
+                            if (!task_active) {
+                                AATask t = aa_stack[--aa_top];
+                                t_cx = t.cx;
+                                t_cy = t.cy;
+                                t_level = t.level;
+                                t_corner = 0;
+                                t_all_equal = true;
+                                task_active = true;
+                            }
+                            // box of this task: pixel size halved (aa_iter - level) times (main.cu:251,297)
+                            float sx = pix_w, sy = pix_h;
+                            for (uint32_t k = t_level; k < aa_iter; ++k) {
+                                sx = sx * 0.5f;
+                                sy = sy * 0.5f;
+                            }
+                            float hx = sx * 0.5f, hy = sy * 0.5f;
+                            float ox = (t_corner & 1u) ? 1.0f : -1.0f, oy = (t_corner & 2u) ? 1.0f : -1.0f;
+                            float rx, ry;
+                            if (t_level == 0u) {
+                                rx = t_cx;
+                                ry = t_cy;
+                            } else if (t_level == 1u) {
+                                rx = t_cx + ox * hx * 0.5f;
+                                ry = t_cy + oy * hy * 0.5f;
                             } else {
-                                float sx = pix_w, sy = pix_h;
-                                for (uint32_t k = t_level; k < aa_iter; ++k) {
-                                    sx = sx * 0.5f;
-                                    sy = sy * 0.5f;
-                                }
-                                float hx = sx * 0.5f, hy = sy * 0.5f;
-                                for (uint32_t c = 0; c < 4u; ++c) {
-                                    float ox = (c & 1u) ? 1.0f : -1.0f, oy = (c & 2u) ? 1.0f : -1.0f;
-                                    aa_stack[aa_top++] = AATask{t_cx + ox * hx * 0.5f, t_cy + oy * hy * 0.5f, t_level - 1u};
+                                rx = t_cx + ox * hx;
+                                ry = t_cy + oy * hy;
+                            }
+                            // Camera::getRay (Camera.hpp:86-144)
+                            V3 ro, rd;
+                            if (cam_type == CRT_CAM_ORTHOGRAPHIC) {
+                                ro = ((cam_right * rx) * ortho + (cam_up * ry) * ortho) + cam_pos;
+                                rd = ray_dir(cam_front);
+                            } else {
+                                ro = (cam_right * rx + cam_up * ry) + cam_pos;
+                                rd = ray_dir(ro - eye);
+                            }
+                            cur_o = ro;
+                            cur_d = rd;
+                            cur_att = V4{1.0f, 1.0f, 1.0f, 1.0f};
+                            cur_ref = a.ref_iter;
+                            cur_depth = a.gl_iter;
+                            cur_valid = true;
+                            color_active = true;
+                            final_c = V4{0, 0, 0, 0};
+                            ray_d = mk3(0.0f, 0.0f, -1.0f);
+                            nframes = 0;
+                            on_stack = 0;
+                        }
+                    } else if (nframes == 0) {
+                        // color() returned: hand the colour to the AA task (main.cu:254-300)
+                        color_active = false;
+                        float mult = 1.0f / (float)(1u << (2u * (aa_iter - t_level)));
+                        if (t_level == 0u) {
+                            acc = acc + final_c * mult;
+                            task_active = false;
+                        } else if (t_level == 1u) {
+                            acc = acc + (final_c * mult) * 0.25f;
+                            if (++t_corner == 4u) task_active = false;
+                        } else {
+                            if (t_corner == 0u) t_c0 = final_c;
+                            else if (t_all_equal && !equal4(final_c, t_c0)) t_all_equal = false;
+                            if (++t_corner == 4u) {
+                                task_active = false;
+                                if (t_all_equal) {
+                                    acc = acc + t_c0 * mult;
+                                } else {
+                                    float sx = pix_w, sy = pix_h;
+                                    for (uint32_t k = t_level; k < aa_iter; ++k) {
+                                        sx = sx * 0.5f;
+                                        sy = sy * 0.5f;
+                                    }
+                                    float hx = sx * 0.5f, hy = sy * 0.5f;
+                                    for (uint32_t c = 0; c < 4u; ++c) {
+                                        float ox = (c & 1u) ? 1.0f : -1.0f, oy = (c & 2u) ? 1.0f : -1.0f;
+                                        aa_stack[aa_top++] =
+                                            AATask{t_cx + ox * hx * 0.5f, t_cy + oy * hy * 0.5f, t_level - 1u};
+                                    }
                                 }
                             }
                         }
+                    } else {
+                        // pop the next child of the innermost frame
+                        Frame& f = frames[nframes - 1];
+                        Rng rv;
+                        rv.v0 = f.rng[0];
+                        rv.v1 = f.rng[1];
+                        rv.v2 = f.rng[2];
+                        rv.v3 = f.rng[3];
+                        rv.v4 = f.rng[4];
+                        rv.d = f.rng[5];
+                        float r2 = rng_current_uniform(rv);
+                        rng_unstep(rv);
+                        float r1 = rng_current_uniform(rv);
+                        rng_unstep(rv);
+                        V3 hp = ld3(f.P), hn = ld3(f.N);
+                        V4 patt = ld4(f.att);
+                        V4 pdiff = ld4c(sc->shade[f.geom].diffuse);
+                        uint32_t cdepth = f.child_depth;
+                        uint32_t rem = f.remaining - 1u;
+                        if (rem == 0u) {
+                            --nframes;
+                        } else {
+                            f.remaining = rem;
+                            f.rng[0] = rv.v0;
+                            f.rng[1] = rv.v1;
+                            f.rng[2] = rv.v2;
+                            f.rng[3] = rv.v3;
+                            f.rng[4] = rv.v4;
+                            f.rng[5] = rv.d;
+                        }
+                        --on_stack;
+                        // get_random_ray_values_in_hemisphere (main.cu:60-74)
+                        V3 Nx, Nz;
+                        surface_frame(hn, Nx, Nz);
+                        const float PI_2 = 6.28318530717958647692f;
+                        float sinTheta = 1.0f - r1 * r1;
+                        float phi = r2 * PI_2;
+                        float sp, cp;
+                        sincos_c(phi, sp, cp);
+                        float x = sinTheta * cp, z = sinTheta * sp;
+                        V3 w = mk3(x * Nz.x + r1 * hn.x + z * Nx.x, x * Nz.y + r1 * hn.y + z * Nx.y,
+                                   x * Nz.z + r1 * hn.z + z * Nx.z);
+                        cur_o = hp + w * 0.01f;
+                        cur_d = w;
+                        cur_att = ((pdiff * (2.0f * r1)) * patt) * inv_ind; // main.cu:186
+                        cur_ref = a.ref_iter;
+                        cur_depth = cdepth;
+                        cur_valid = true;
                     }
-                    continue;
                 }
-                // pop the next child of the innermost frame
-                Frame& f = frames[nframes - 1];
-                Rng rv;
-                rv.v0 = f.rng[0];
-                rv.v1 = f.rng[1];
-                rv.v2 = f.rng[2];
-                rv.v3 = f.rng[3];
-                rv.v4 = f.rng[4];
-                rv.d = f.rng[5];
-                float r2 = rng_current_uniform(rv);
-                rng_unstep(rv);
-                float r1 = rng_current_uniform(rv);
-                rng_unstep(rv);
-                V3 hp = ld3(f.P), hn = ld3(f.N);
-                V4 patt = ld4(f.att);
-                const DevGeom& pg = sc->geom[f.geom];
-                uint32_t cdepth = f.child_depth;
-                uint32_t rem = f.remaining - 1u;
-                if (rem == 0u) {
-                    --nframes;
-                } else {
-                    f.remaining = rem;
-                    f.rng[0] = rv.v0;
-                    f.rng[1] = rv.v1;
-                    f.rng[2] = rv.v2;
-                    f.rng[3] = rv.v3;
-                    f.rng[4] = rv.v4;
-                    f.rng[5] = rv.d;
+                if (cur_valid) {
+                    // ---- pop (main.cu:132-147)
+                    cur_valid = false;
+                    if (cur_ref != 0u) {
+                        if (!eps_equal(len_sq(cur_d), 0.0f, kEpsSq)) ray_d = normalize3(cur_d);
+                        const V3 ro = cur_o;
+                        Hit h = closest_hit(sc, ro, ray_d, 0.0f);
+                        if (h.idx < 0) {
+                            final_c = final_c + cur_att * V4{0.0f, 0.0f, 0.0f, 1.0f}; // Color::black()
+                        } else {
+                            V3 P, N;
+                            hit_point_normal(sc, h, ro, ray_d, P, N);
+                            if (h.mat_type == CRT_MAT_DIFFUSE) {
+                                have_node = true;
+                                n_P = P;
+                                n_N = N;
+                                n_view = neg(cur_d); // viewDir = -state.r_dir, the stored (un-normalised) direction
+                                n_att = cur_att;
+                                n_geom = (uint32_t)h.idx;
+                                n_depth = cur_depth;
+                            } else if (h.mat_type == CRT_MAT_REFLECT) {
+                                // get_reflect_ray (main.cu:76-81)
+                                V3 I = normalize3(ray_d);
+                                V3 rdir = reflect3(I, normalize3(N));
+                                cur_o = P + rdir * 0.01f;
+                                cur_d = rdir;
+                                cur_att = cur_att * ld4c(sc->shade[h.idx].diffuse);
+                                cur_ref = cur_ref - 1u;
+                                cur_valid = true;
+                            } else {
+                                // get_refraction_ray (main.cu:83-108)
+                                bool front_face = dot3(ray_d, N) < 0.0f;
+                                V3 norm = front_face ? N : neg(N);
+                                float ratio = sc->shade[h.idx].refract_index / 1.0f;
+                                if (front_face) ratio = rcp_exact(ratio);
+                                V3 rdn = normalize3(ray_d);
+                                float cos_theta = __builtin_fminf(dot3(neg(rdn), norm), 1.0f);
+                                float sin_theta = rcp_exact(rsqrt_c(1.0f - cos_theta * cos_theta));
+                                bool cannot_refract = ratio * sin_theta > 1.0f; // reflectance(...) > 1 never holds
+                                V3 dir = cannot_refract ? reflect3(rdn, norm) : refract3(rdn, norm, ratio);
+                                cur_o = P + dir * 0.01f;
+                                cur_d = dir;
+                                cur_att = cur_att * ld4c(sc->shade[h.idx].diffuse);
+                                cur_ref = cur_ref - 1u;
+                                cur_valid = true;
+                            }
+                        }
+                    }
                 }
-                --on_stack;
-                // get_random_ray_values_in_hemisphere (main.cu:60-74)
-                V3 Nx, Nz;
-                surface_frame(hn, Nx, Nz);
-                const float PI_2 = 6.28318530717958647692f;
-                float sinTheta = 1.0f - r1 * r1;
-                float phi = r2 * PI_2;
-                float sp, cp;
-                sincos_c(phi, sp, cp);
-                float x = sinTheta * cp, z = sinTheta * sp;
-                V3 w = mk3(x * Nz.x + r1 * hn.x + z * Nx.x, x * Nz.y + r1 * hn.y + z * Nx.y, x * Nz.z + r1 * hn.z + z * Nx.z);
-                cur_o = hp + w * 0.01f;
-                cur_d = w;
-                cur_att = ((ld4(pg.diffuse) * (2.0f * r1)) * patt) * inv_ind; // main.cu:186
-                cur_ref = a.ref_iter;
-                cur_depth = cdepth;
-                cur_valid = true;
             }
-            // ---- pop (main.cu:132-147)
-            cur_valid = false;
-            if (cur_ref == 0u) continue;
-            if (!eps_equal(len_sq(cur_d), 0.0f, kEpsSq)) ray_d = normalize3(cur_d);
-            const V3 ro = cur_o;
-            Hit h = closest_hit(sc, ro, ray_d, 0.0f);
-            if (h.idx < 0) {
-                final_c = final_c + cur_att * V4{0.0f, 0.0f, 0.0f, 1.0f}; // Color::black()
+        }
+        if (!__any(have_node)) break; // every lane is out of pixels
+
+        // ===================== phase B: shade the diffuse hits (main.cu:153-195)
+        const bool act = have_node;
+        if (act) ++cnt_shade;
+        const DevGeomShade CRT_CONST* gs = &sc->shade[act ? n_geom : 0u];
+        V4 direct = V4{0, 0, 0, 0}; // LightList::calculateColor (LightList.hpp:23-36)
+        const uint32_t n_lights = sc->n_lights;
+        for (uint32_t li = 0; li < n_lights; ++li) {
+            const DevLight CRT_CONST* L = &sc->lights[li];
+            if (L->kind != CRT_LIGHT_AREA) {
+                if (act) direct = direct + point_light_color(sc, L, gs, n_P, n_N, n_view);
                 continue;
             }
-            const DevGeom& g = sc->geom[h.idx];
-            V3 P, N;
-            hit_point_normal(sc, h, ro, ray_d, P, N);
-            if (g.mat_type == CRT_MAT_DIFFUSE) {
-                have_node = true;
-                n_P = P;
-                n_N = N;
-                n_view = neg(cur_d); // viewDir = -state.r_dir, the stored (un-normalised) direction
-                n_att = cur_att;
-                n_geom = (uint32_t)h.idx;
-                n_depth = cur_depth;
-            } else if (g.mat_type == CRT_MAT_REFLECT) {
-                // get_reflect_ray (main.cu:76-81)
-                V3 I = normalize3(ray_d);
-                V3 rdir = reflect3(I, normalize3(N));
-                cur_o = P + rdir * 0.01f;
-                cur_d = rdir;
-                cur_att = cur_att * ld4(g.diffuse);
-                cur_ref = cur_ref - 1u;
-                cur_valid = true;
-            } else {
-                // get_refraction_ray (main.cu:83-108)
-                bool front_face = dot3(ray_d, N) < 0.0f;
-                V3 norm = front_face ? N : neg(N);
-                float ratio = g.refract_index / 1.0f;
-                if (front_face) ratio = 1.0f / ratio;
-                V3 rdn = normalize3(ray_d);
-                float cos_theta = __builtin_fminf(dot3(neg(rdn), norm), 1.0f);
-                float sin_theta = 1.0f / rsqrt_c(1.0f - cos_theta * cos_theta);
-                bool cannot_refract = ratio * sin_theta > 1.0f; // reflectance(...) > 1 never holds
-                V3 dir = cannot_refract ? reflect3(rdn, norm) : refract3(rdn, norm, ratio);
-                cur_o = P + dir * 0.01f;
-                cur_d = dir;
-                cur_att = cur_att * ld4(g.diffuse);
-                cur_ref = cur_ref - 1u;
-                cur_valid = true;
+            if (!L->initialized) { // AreaLight.hpp:586
+                if (act) {
+                    V3 amb = mk3(gs->ambient[0], gs->ambient[1], gs->ambient[2]) * ld3c(L->color);
+                    direct = direct + V4{amb.x, amb.y, amb.z, 1.0f};
+                }
+                continue;
             }
-        }
-        if (done) break;
-
-        // ================= phase B: shade the diffuse hit (main.cu:153-195)
-        const DevGeom& g = sc->geom[n_geom];
-        ++cnt_shade;
-        V4 direct = V4{0, 0, 0, 0}; // LightList::calculateColor (LightList.hpp:23-36)
-        for (uint32_t li = 0; li < sc->n_lights; ++li) {
-            const DevLight& L = sc->lights[li];
-            V4 c = (L.kind == CRT_LIGHT_AREA) ? area_light_color(sc, ltc, L, g, n_P, n_N, n_view, rng)
-                                              : point_light_color(sc, L, g, n_P, n_N, n_view);
-            direct = direct + c;
-        }
-        if (n_depth > 0u) {
-            ++cnt_expand;
-            // The reference draws (r1,r2) for every child and pushes while its stack has room (main.cu:176-191).
-            uint32_t room = on_stack < CRT_RAY_STACK ? CRT_RAY_STACK - on_stack : 0u;
-            uint32_t accepted = a.ind_rays < room ? a.ind_rays : room;
-            for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
-            if (accepted > 0u) {
-                Frame& f = frames[nframes++];
-                f.P[0] = n_P.x; f.P[1] = n_P.y; f.P[2] = n_P.z;
-                f.N[0] = n_N.x; f.N[1] = n_N.y; f.N[2] = n_N.z;
-                f.att[0] = n_att.x; f.att[1] = n_att.y; f.att[2] = n_att.z; f.att[3] = n_att.w;
-                f.rng[0] = rng.v0; f.rng[1] = rng.v1; f.rng[2] = rng.v2;
-                f.rng[3] = rng.v3; f.rng[4] = rng.v4; f.rng[5] = rng.d;
-                f.geom = n_geom;
-                f.remaining = accepted;
-                f.child_depth = n_depth - 1u;
-                on_stack += accepted;
+            // ---- _calculateVisibility (AreaLight.hpp:484-529)
+            const uint32_t S = L->shadow_samples;
+            const uint32_t n_geom_all = sc->n_geom;
+            const V3 lpos = ld3c(L->pos);
+            const V3 lp0 = ld3c(L->p0), lp2 = ld3c(L->p2);
+            const V3 le01 = ld3c(L->e01), le03 = ld3c(L->e03), le23 = ld3c(L->e23), le21 = ld3c(L->e21);
+            uint32_t shadowed = 0;
+            uint32_t qcount = 0; // wave-uniform
+            s_shadow[lane] = 0u;
+            for (uint32_t s = 0; s < S; ++s) {
+                bool glass = false;
+                V3 so = mk3(0, 0, 0), sd = mk3(0, 0, 0);
+                Hit h;
+                h.idx = -1;
+                h.mat_type = 0;
+                h.t = kFltMax;
+                h.u = h.v = 0.0f;
+                if (act) {
+                    float u = rng_uniform(rng);
+                    float v = rng_uniform(rng);
+                    V3 sample; // _randomPoint (AreaLight.hpp:340-375)
+                    if (u + v < 1.0f) {
+                        sample = ((lp0 + le01 * u) + le03 * v) + lpos;
+                    } else {
+                        u = 1.0f - u;
+                        v = 1.0f - v;
+                        sample = ((lp2 + le23 * u) + le21 * v) + lpos;
+                    }
+                    V3 dir = sample - n_P;
+                    float dist = length3(dir);
+                    if (!eps_equal(dist, 0.0f, kEps)) dir = normalize3(dir);
+                    so = n_P + dir * 0.01f;
+                    sd = ray_dir(dir);                      // the Ray ctor normalises once more (Ray.hpp:45-52)
+                    const float maxd = max_std(0.0f, dist); // Ray::setDistance
+                    // first pass of Light::_isCovered (Light.hpp:41-46): closest hit decides
+                    const float dd = dot3(sd, sd);
+                    for (uint32_t i = 0; i < n_geom_all; ++i) {
+                        const DevGeomHot CRT_CONST* g = &sc->hot[i];
+                        const uint32_t kind = g->kind, mat = g->mat_type;
+                        const V3 go = ld3c(g->o), gn = ld3c(g->n);
+                        float t = 0.0f, uu = 0.0f, vv = 0.0f;
+                        bool hit;
+                        if (kind == CRT_GEOM_SPHERE) {
+                            hit = sphere_t(go, gn.x, so, sd, dd, maxd, t);
+                        } else {
+                            V3 p = so - go;
+                            hit = quad_plane_t(p, sd, gn, maxd, h.t, t);
+                            if (hit) {
+                                UVRec q = load_uv(&sc->uv[i]);
+                                hit = quad_uv<false>(q, p, sd, t, uu, vv);
+                            }
+                        }
+                        if (hit && !(t > h.t)) {
+                            h.idx = (int)i;
+                            h.mat_type = mat;
+                            h.t = t;
+                            h.u = uu;
+                            h.v = vv;
+                        }
+                    }
+                    if (h.idx >= 0) {
+                        if (h.mat_type != CRT_MAT_REFRACTIVE) ++shadowed;
+                        else glass = true;
+                    }
+                }
+                // ---- queue the glass continuation (rare) instead of walking it with 63 lanes idle
+                const uint64_t gm = __ballot(glass);
+                if (gm != 0) {
+                    if (glass) {
+                        const uint32_t slot = qcount + lane_rank(gm);
+                        q_f[0][slot] = so.x;
+                        q_f[1][slot] = so.y;
+                        q_f[2][slot] = so.z;
+                        q_f[3][slot] = sd.x;
+                        q_f[4][slot] = sd.y;
+                        q_f[5][slot] = sd.z;
+                        q_f[6][slot] = h.t;
+                        q_f[7][slot] = h.u;
+                        q_f[8][slot] = h.v;
+                        q_meta[slot] = (uint32_t)h.idx | (lane << 16);
+                    }
+                    qcount += (uint32_t)__popcll(gm);
+                }
+                const bool last = (s + 1u == S);
+                if (qcount >= 64u || (last && qcount > 0u)) {
+                    __syncthreads();
+                    do { // one batch of 64 in mid-loop (fewer than 64 stay queued), everything after the last sample
+                        const uint32_t n = qcount < 64u ? qcount : 64u;
+                        const uint32_t base = qcount - n;
+                        if (lane < n) {
+                            const uint32_t slot = base + lane;
+                            V3 o = mk3(q_f[0][slot], q_f[1][slot], q_f[2][slot]);
+                            V3 d = mk3(q_f[3][slot], q_f[4][slot], q_f[5][slot]);
+                            Hit qh;
+                            const uint32_t meta = q_meta[slot];
+                            qh.idx = (int)(meta & 0xffffu);
+                            qh.mat_type = CRT_MAT_REFRACTIVE;
+                            qh.t = q_f[6][slot];
+                            qh.u = q_f[7][slot];
+                            qh.v = q_f[8][slot];
+                            if (covered_through_glass(sc, L, o, d, qh)) atomicAdd(&s_shadow[meta >> 16], 1u);
+                        }
+                        qcount = base;
+                    } while (last && qcount > 0u);
+                    __syncthreads();
+                }
             }
-            for (uint32_t k = 2u * accepted; k < 2u * a.ind_rays; ++k) rng_step(rng);
+            if (act) {
+                shadowed += s_shadow[lane];
+                float visibility = 1.0f - ((float)shadowed / (float)S);
+                direct = direct + area_light_shade(ltc, L, gs, n_P, n_N, n_view, visibility);
+            }
+            __syncthreads(); // s_shadow is reset at the top of the next light
         }
-        final_c = final_c + n_att * direct;
+        if (act) {
+            if (n_depth > 0u) {
+                ++cnt_expand;
+                // The reference draws (r1,r2) for every child and pushes while its stack has room (main.cu:176-191).
+                uint32_t room = on_stack < CRT_RAY_STACK ? CRT_RAY_STACK - on_stack : 0u;
+                uint32_t accepted = a.ind_rays < room ? a.ind_rays : room;
+                for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
+                if (accepted > 0u) {
+                    Frame& f = frames[nframes++];
+                    f.P[0] = n_P.x; f.P[1] = n_P.y; f.P[2] = n_P.z;
+                    f.N[0] = n_N.x; f.N[1] = n_N.y; f.N[2] = n_N.z;
+                    f.att[0] = n_att.x; f.att[1] = n_att.y; f.att[2] = n_att.z; f.att[3] = n_att.w;
+                    f.rng[0] = rng.v0; f.rng[1] = rng.v1; f.rng[2] = rng.v2;
+                    f.rng[3] = rng.v3; f.rng[4] = rng.v4; f.rng[5] = rng.d;
+                    f.geom = n_geom;
+                    f.remaining = accepted;
+                    f.child_depth = n_depth - 1u;
+                    on_stack += accepted;
+                }
+                for (uint32_t k = 2u * accepted; k < 2u * a.ind_rays; ++k) rng_step(rng);
+            }
+            final_c = final_c + n_att * direct;
+            have_node = false;
+        }
     }
-
-    // render() epilogue (main.cu:339-346)
-    out[pm.out_index] = make_float4(saturate_c(acc.x), saturate_c(acc.y), saturate_c(acc.z), saturate_c(acc.w));
-    a.rng[0 * npix + pix] = rng.v0;
-    a.rng[1 * npix + pix] = rng.v1;
-    a.rng[2 * npix + pix] = rng.v2;
-    a.rng[3 * npix + pix] = rng.v3;
-    a.rng[4 * npix + pix] = rng.v4;
-    a.rng[5 * npix + pix] = rng.d;
-    a.counters[pix] += cnt_shade;
-    a.counters[npix + pix] += cnt_expand;
 }
 
 // Scatter of gathered shard buffers into the row-major framebuffer.
@@ -525,16 +684,58 @@ __global__ void __launch_bounds__(64) scatter_kernel(uint32_t nx, uint32_t ny, u
     if (i < nx && j < ny) fb[(size_t)j * nx + i] = gathered[((size_t)rank * tiles_max + k) * 64u + lane];
 }
 
+// Exhaustive check of rcp_exact against the IEEE quotient; bits = blockIdx-strided sweep of all 2^32 patterns.
+__global__ void __launch_bounds__(256) selftest_rcp_kernel(unsigned long long* __restrict__ mismatches,
+                                                           uint32_t* __restrict__ first_bad) {
+    unsigned long long bad = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += stride) {
+        float x = __uint_as_float((uint32_t)b);
+        float r = rcp_exact(x);
+        float q = 1.0f / x;
+        bool same = (__float_as_uint(r) == __float_as_uint(q)) || (r != r && q != q);
+        if (!same) {
+            ++bad;
+            atomicMin(first_bad, (uint32_t)b);
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 void launch_random_init(uint32_t npix, uint64_t seed, uint32_t* state, hipStream_t stream) {
     hipLaunchKernelGGL(random_init_kernel, dim3((npix + 63u) / 64u), dim3(64), 0, stream, npix, seed, state);
 }
-void launch_render(const RenderArgs& args, uint32_t waves, hipStream_t stream) {
-    hipLaunchKernelGGL(render_kernel, dim3(waves), dim3(64), 0, stream, args);
+hipError_t launch_render(const RenderArgs& args, hipStream_t stream) {
+    // Persistent grid: as many one-wave workgroups as the device keeps resident, never more than there are units.
+    static int resident_waves[64] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (resident_waves[dev] == 0) {
+        int per_cu = 0, cus = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, 64, 0);
+        if (e != hipSuccess) return e;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 16) per_cu = 16; // 4 waves per SIMD saturate VALU issue
+        resident_waves[dev] = per_cu * cus;
+    }
+    if (args.n_units == 0) return hipSuccess;
+    uint32_t grid = args.n_units < (uint32_t)resident_waves[dev] ? args.n_units : (uint32_t)resident_waves[dev];
+    e = hipMemsetAsync(args.unit_counter, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(render_kernel, dim3(grid), dim3(64), 0, stream, args);
+    return hipGetLastError();
 }
 void launch_scatter(uint32_t nx, uint32_t ny, uint32_t tiles_x, uint32_t tiles_y, uint32_t world, uint32_t tiles_max,
                     const float* gathered, float* fb, hipStream_t stream) {
     hipLaunchKernelGGL(scatter_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, stream, nx, ny, tiles_x, tiles_y, world,
                        tiles_max, reinterpret_cast<const float4*>(gathered), reinterpret_cast<float4*>(fb));
+}
+void launch_selftest_rcp(unsigned long long* mismatches, uint32_t* first_bad, hipStream_t stream) {
+    hipLaunchKernelGGL(selftest_rcp_kernel, dim3(4096), dim3(256), 0, stream, mismatches, first_bad);
 }
 
 } // namespace crt

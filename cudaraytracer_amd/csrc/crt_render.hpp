@@ -19,6 +19,8 @@ struct RenderArgs {
     uint32_t* rng;    // 6 planes of nx*ny words: v0..v4, d
     uint32_t* counters; // 2 planes of nx*ny words: shaded diffuse hits, expanding hits (accumulated)
     float* out;
+    uint32_t* unit_counter; // global work-unit cursor (zeroed by launch_render)
+    uint32_t n_units;       // 64-pixel work units in this launch
     uint32_t nx, ny;
     uint32_t aa_iter, ref_iter, gl_iter, ind_rays;
     uint32_t mode;
@@ -28,7 +30,8 @@ struct RenderArgs {
 };
 
 void launch_random_init(uint32_t npix, uint64_t seed, uint32_t* state, hipStream_t stream);
-void launch_render(const RenderArgs& args, uint32_t waves, hipStream_t stream);
+hipError_t launch_render(const RenderArgs& args, hipStream_t stream);
+void launch_selftest_rcp(unsigned long long* mismatches, uint32_t* first_bad, hipStream_t stream);
 void launch_scatter(uint32_t nx, uint32_t ny, uint32_t tiles_x, uint32_t tiles_y, uint32_t world, uint32_t tiles_max,
                     const float* gathered, float* fb, hipStream_t stream);
 

@@ -75,7 +75,19 @@ void fail(char* err, size_t cap, const char* msg) {
 
 } // namespace
 
-int flatten_scene(const crt_scene_desc* in, DevScene* out, const float* /*ltc_tables*/, char* err, size_t errcap) {
+static void fill_uv(DevGeomUV& d, const QuadConst& q) {
+    d.idu = q.idu;
+    d.idv = q.idv;
+    d.linear = q.linear;
+    d.nor_id = q.nor_id;
+    memcpy(d.ka, q.ka, 8);
+    memcpy(d.kb, q.kb, 8);
+    memcpy(d.kg, q.kg, 8);
+    d.k2 = q.k2;
+    d.pad = 0.0f;
+}
+
+int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t errcap) {
     if (!in || !out) {
         fail(err, errcap, "flatten_scene: null argument");
         return CRT_ERR_INVALID;
@@ -111,7 +123,8 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, const float* /*ltc_ta
     out->n_geom = in->n_geometry;
     for (uint32_t i = 0; i < in->n_geometry; ++i) {
         const crt_geometry& g = in->geometry[i];
-        DevGeom& d = out->geom[i];
+        DevGeomHot& h = out->hot[i];
+        DevGeomShade& d = out->shade[i];
         if (g.kind != CRT_GEOM_SPHERE && g.kind != CRT_GEOM_QUAD) {
             fail(err, errcap, "scene: unknown geometry kind");
             return CRT_ERR_INVALID;
@@ -120,8 +133,8 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, const float* /*ltc_ta
             fail(err, errcap, "scene: unknown material type");
             return CRT_ERR_INVALID;
         }
-        d.kind = g.kind;
-        d.mat_type = g.mat.type;
+        h.kind = g.kind;
+        h.mat_type = g.mat.type;
         memcpy(d.ambient, g.mat.ambient, 16);
         memcpy(d.diffuse, g.mat.diffuse, 16);
         memcpy(d.specular, g.mat.specular, 16);
@@ -135,25 +148,14 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, const float* /*ltc_ta
         uint32_t col = (fx >= 0.0f && fx < 4294967296.0f) ? (uint32_t)fx : 0xFFFFFFFFu;
         d.ltc_col = col < 64u ? col : 0xFFFFFFFFu; // out of range -> getPixelColor returns zeros
         if (g.kind == CRT_GEOM_SPHERE) {
-            memcpy(d.center, g.center, 12);
-            d.radius = g.radius;
-            d.radius_sq = g.radius * g.radius;
+            memcpy(h.o, g.center, 12);
+            h.n[0] = g.radius * g.radius;
         } else {
             F3 p0 = ld(g.v[0].pos);
             QuadConst q = quad_constants(p0, ld(g.v[1].pos), ld(g.v[2].pos), ld(g.v[3].pos));
-            st(d.v0, p0);
-            st(d.a, q.a);
-            st(d.b, q.b);
-            st(d.nor, q.nor);
-            d.id = q.id;
-            d.idu = q.idu;
-            d.idv = q.idv;
-            memcpy(d.ka, q.ka, 8);
-            memcpy(d.kb, q.kb, 8);
-            memcpy(d.kg, q.kg, 8);
-            d.k2 = q.k2;
-            d.nor_id = q.nor_id;
-            d.linear = q.linear;
+            st(h.o, p0);
+            st(h.n, q.nor);
+            fill_uv(out->uv[i], q);
             for (int k = 0; k < 4; ++k) memcpy(d.n[k], g.v[k].normal, 12);
         }
     }
@@ -179,27 +181,18 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, const float* /*ltc_ta
             for (int k = 0; k < 4; ++k) {
                 p[k] = ld(l.points[k]);
                 w[k] = add(pos, p[k]);
-                st(d.p[k], p[k]);
                 st(d.pts[k], w[k]);
             }
+            st(d.p0, p[0]);
+            st(d.p2, p[2]);
             st(d.e01, sub(p[1], p[0]));
             st(d.e03, sub(p[3], p[0]));
             st(d.e23, sub(p[3], p[2]));
             st(d.e21, sub(p[1], p[2]));
             st(d.light_normal, cross(sub(w[1], w[0]), sub(w[3], w[0])));
             QuadConst q = quad_constants(p[0], p[1], p[2], p[3]);
-            st(d.a, q.a);
-            st(d.b, q.b);
             st(d.nor, q.nor);
-            d.id = q.id;
-            d.idu = q.idu;
-            d.idv = q.idv;
-            memcpy(d.ka, q.ka, 8);
-            memcpy(d.kb, q.kb, 8);
-            memcpy(d.kg, q.kg, 8);
-            d.k2 = q.k2;
-            d.nor_id = q.nor_id;
-            d.linear = q.linear;
+            fill_uv(d.uv, q);
         }
     }
     return CRT_OK;

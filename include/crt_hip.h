@@ -208,6 +208,13 @@ int crt_scatter_shards(crt_ctx* ctx, uint32_t nx, uint32_t ny, uint32_t world,
  * (computed from the RNG draw counters and the settings).  Synchronous. */
 int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out);
 
+/* Device self-test: compares the kernels' fast correctly-rounded reciprocal with
+ * the IEEE quotient 1.0f/x for all 2^32 float bit patterns.  Returns the number
+ * of mismatches (expected 0) and the smallest mismatching bit pattern
+ * (0xFFFFFFFF if none).  Synchronous, about a second.  No counterpart in the
+ * reference. */
+int crt_selftest_rcp(crt_ctx* ctx, uint64_t* mismatches, uint32_t* first_bad_bits);
+
 /* ---- device-buffer helpers for hosts without their own allocator -------- */
 int crt_fb_alloc(crt_ctx* ctx, size_t n_floats, float** out_dev);
 int crt_fb_free(crt_ctx* ctx, float* dev);

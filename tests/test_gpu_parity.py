@@ -81,3 +81,10 @@ def test_second_render_continues_streams(gpu_ctx, oracle):
     assert np.array_equal(a, ra) and np.array_equal(b, rb)
     assert not np.array_equal(a, b)
     assert np.array_equal(gpu_ctx.rng_export(32, 32), s2)
+
+
+def test_fast_reciprocal_is_correctly_rounded(gpu_ctx):
+    """The kernels' reciprocal (hardware estimate + two fused Newton steps) must equal the IEEE
+    quotient 1.0f/x for every one of the 2^32 float bit patterns."""
+    bad, first = gpu_ctx.selftest_rcp()
+    assert bad == 0, f"{bad} mismatching inputs, first bit pattern 0x{first:08x}"
