@@ -34,7 +34,8 @@ def algorithmic_flops(stats):
 
 def stats_dict(s):
     return {"rng_draws": int(s.rng_draws), "shadow_samples": int(s.shadow_samples),
-            "shade_points": int(s.shade_points), "gi_children": int(s.gi_children)}
+            "shade_points": int(s.shade_points), "gi_children": int(s.gi_children),
+            "exact_tests": int(s.exact_tests), "glass_walks": int(s.glass_walks)}
 
 
 def diff(a, b):

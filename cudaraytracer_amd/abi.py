@@ -60,7 +60,7 @@ class crt_settings(C.Structure):
 
 class crt_stats(C.Structure):
     _fields_ = [("rng_draws", C.c_uint64), ("shadow_samples", C.c_uint64), ("shade_points", C.c_uint64),
-                ("gi_children", C.c_uint64)]
+                ("gi_children", C.c_uint64), ("exact_tests", C.c_uint64), ("glass_walks", C.c_uint64)]
 
 
 def make_settings(nx=720, ny=720, aa_iter=1, ref_iter=4, gl_iter=2, ind_rays=75, shadowSamples=50,

@@ -75,6 +75,7 @@ crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
     a.rng = ctx->rng_dev;
     a.counters = ctx->counters_dev;
     a.unit_counter = ctx->unit_counter;
+    a.wave_tallies = reinterpret_cast<unsigned long long*>(ctx->unit_counter + 16);
     a.out = out;
     a.nx = st->nx;
     a.ny = st->ny;
@@ -166,6 +167,7 @@ int crt_rng_init(crt_ctx* ctx, uint32_t nx, uint32_t ny, uint64_t seed, void* st
     HIP_TRY(ctx, hipMemcpyAsync(ctx->rng_init_d, ctx->rng_dev + 5 * npix, npix * sizeof(uint32_t),
                                 hipMemcpyDeviceToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->counters_dev, 0, npix * 2 * sizeof(uint32_t), s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->unit_counter + 16, 0, 16, s));
     return CRT_OK;
 }
 
@@ -295,6 +297,10 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out) {
     out->shade_points = shade;
     out->gi_children = expand * (uint64_t)st->ind_rays;
     out->shadow_samples = (draws - 2u * out->gi_children) / 2u;
+    unsigned long long tallies[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpy(tallies, ctx->unit_counter + 16, 16, hipMemcpyDeviceToHost));
+    out->exact_tests = tallies[0];
+    out->glass_walks = tallies[1];
     return CRT_OK;
 }
 

@@ -72,6 +72,29 @@ DI float rcp_exact(float x) {
     return 1.0f / x;
 }
 
+// Unchecked variants for operands the caller has already bounded to [2^-100, 2^100].
+DI float rcp_nr(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    return r;
+}
+// Correctly rounded square root of a normal-range operand: hardware estimate (1 ulp), then pick
+// among it and its two neighbours by the sign of the fused residuals (verified exhaustively by
+// crt_selftest against sqrtf).
+DI float sqrt_nr(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    float r_dn = __builtin_fmaf(-s_dn, s, x);
+    float r_up = __builtin_fmaf(-s_up, s, x);
+    s = (r_dn <= 0.0f) ? s_dn : s;
+    s = (r_up > 0.0f) ? s_up : s;
+    return s;
+}
+
 // vec::dot accumulates from zero in index order (vec.hpp:428-434).
 DI float dot3(V3 a, V3 b) {
     float r = 0.0f + a.x * b.x;
@@ -81,19 +104,35 @@ DI float dot3(V3 a, V3 b) {
 }
 DI float len_sq(V3 a) { return dot3(a, a); }
 DI float rsqrt_c(float x) { return rcp_exact(__builtin_sqrtf(x)); } // rsqrtf in IEEE form
-DI float length3(V3 a) { return rcp_exact(rsqrt_c(len_sq(a))); }    // vec.hpp:398-409
+// vec::length (vec.hpp:398-409) = 1 / rsqrt(len^2) and vec::normalize (vec.hpp:411-422) = v * (1/len),
+// evaluated as the reference does: sqrt, then three dependent reciprocals.  One range test on
+// len^2 covers the whole chain (len^2 in [2^-80, 2^80] keeps every intermediate in [2^-40, 2^40]).
+__device__ __attribute__((noinline)) float length_slow(float lsq) { return 1.0f / (1.0f / __builtin_sqrtf(lsq)); }
+DI float length_from_sq(float lsq) {
+    if (lsq >= 0x1p-80f && lsq <= 0x1p80f) return rcp_nr(rcp_nr(sqrt_nr(lsq)));
+    return length_slow(lsq);
+}
+DI float length3(V3 a) { return length_from_sq(len_sq(a)); }
 // vec::operator/=(T) (vec.hpp:739-769)
 DI V3 div_s(V3 a, float y) {
     if (y == 0.0f) return a;
     float inv = rcp_exact(y);
     return a * inv;
 }
-// vec::normalize (vec.hpp:411-422)
-DI V3 normalize3(V3 a) {
-    float len = length3(a);
+// length and normalised vector together; `len` is what length3(a) returns.
+DI V3 normalize3_len(V3 a, float& len) {
+    float lsq = len_sq(a);
+    if (lsq >= 0x1p-80f && lsq <= 0x1p80f) {
+        len = rcp_nr(rcp_nr(sqrt_nr(lsq)));
+        return a * rcp_nr(len);
+    }
+    len = length_slow(lsq);
     if (len == 0.0f) return a;
-    float inv = rcp_exact(len);
-    return a * inv;
+    return a * (1.0f / len);
+}
+DI V3 normalize3(V3 a) {
+    float len;
+    return normalize3_len(a, len);
 }
 DI V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 DI bool eps_equal(float a, float b, float e) { return __builtin_fabsf(a - b) < e; } // math_functions.hpp:75-78
@@ -255,6 +294,37 @@ DI bool quad_plane_t(V3 p, V3 d, V3 nor, float dist, float closest, float& t) {
     if (tt < 0.0f || (dist > 0.0f && tt > dist)) return false;
     t = tt;
     return true;
+}
+
+// Conservative filters used by the shadow-ray loop: they return false only when
+// the reference's test of that primitive certainly fails for this ray, using the
+// same operands as the exact test but no division or square root.
+//   sphere (Sphere.hpp:48-96): discr < 0 is the reference's own early-out; with
+//   b > 0 and c > 0 both roots q/a and c/q are negative (q = -0.5(b + sqrt(discr)) < 0),
+//   so the hit is rejected at Sphere.hpp:93-96.  The magnitude bounds keep the
+//   quotients away from underflow, where a rounded -0 would not compare < 0.
+DI bool sphere_may_hit(V3 center, float radius_sq, V3 o, V3 d, float dd4, bool dd_ok) {
+    V3 L = o - center;
+    float b = 2.0f * (d.x * L.x + d.y * L.y + d.z * L.z); // a zero's sign cannot matter below
+    float c = (L.x * L.x + L.y * L.y + L.z * L.z) - radius_sq;
+    float discr = b * b - dd4 * c; // dd4 = 4*(d.d), hoisted by the caller
+    bool behind = dd_ok && b > 1e-30f && b < 1e6f && c > 1e-30f && c < 1e6f;
+    return !(discr < 0.0f || behind);
+}
+//   quad (Quad.hpp:222-226): t = -(pn/dn) is certainly negative when pn*dn > 0, and |t| certainly
+//   exceeds dist when |pn| > |dn|*dist*(1+1e-6) (either it is > dist or it is negative).  The
+//   magnitude bounds keep the rounded quotient away from underflow.  dist_ok = dist in (1e-30, 1e30).
+DI bool plane_may_hit(float pn, float dn, float dist, bool dist_ok) {
+    float adn = __builtin_fabsf(dn);
+    bool neg_t = pn * dn > 1e-24f && adn < 1e6f;
+    float m = (adn * dist) * 1.000001f;
+    bool far_t = dist_ok && __builtin_fabsf(pn) > m && m > 1e-30f;
+    return !(neg_t || far_t);
+}
+DI bool quad_may_hit(V3 p, V3 d, V3 nor, float dist, bool dist_ok) {
+    float pn = p.x * nor.x + p.y * nor.y + p.z * nor.z; // operands as in the exact test; a zero's sign cannot matter
+    float dn = d.x * nor.x + d.y * nor.y + d.z * nor.z;
+    return plane_may_hit(pn, dn, dist, dist_ok);
 }
 
 // Bilinear part of the quad test (Quad.hpp:228-295; AreaLight.hpp:406-480 with

@@ -24,11 +24,16 @@
 //
 // Each wave alternates between phase A, in which lanes step rays (camera rays,
 // GI children, mirror/glass bounces) until each owns a diffuse hit, and phase B,
-// in which all lanes shade their hit together: shadowSamples shadow rays against
-// a scene held in scalar registers, then two LTC polygon integrals.  Shadow rays
-// that meet glass first need the refraction walk of Light::_isCovered; that rare,
-// long path is not taken in place (it would idle the other 63 lanes) but queued
-// in LDS and drained 64 entries at a time with every lane busy.
+// in which all lanes shade their hit together: shadowSamples shadow rays, then
+// two LTC polygon integrals.  The shadow loop is two-stage.  Stage 1 runs per
+// lane and per sample and only *filters*: each primitive (scalar registers) is
+// tested with the conservative, division-free tests of crt_device.hpp; a ray
+// that certainly misses everything is done.  Every other ray is appended to a
+// queue in LDS.  Stage 2 drains that queue 64 rays at a time with all lanes busy
+// and evaluates the reference's exact closest-hit test; rays whose closest hit is
+// glass go to a second queue whose batches run the refraction walk of
+// Light::_isCovered.  Results come back through per-lane counters in LDS.  The
+// rare, long, divergent paths therefore never idle the wave.
 #include <hip/hip_runtime.h>
 
 #include "crt_device.hpp"
@@ -38,7 +43,8 @@ namespace crt {
 
 namespace {
 
-constexpr uint32_t kQueueCap = 128; // >= 63 left over + 64 new entries per sample round
+constexpr uint32_t kRayQueueCap = 192;   // < 64 left over + 2*64 new rays per sample round
+constexpr uint32_t kGlassQueueCap = 128; // < 64 left over + 64 new entries per resolved batch
 
 struct Frame {
     float P[3];      // hit point the children leave from
@@ -179,17 +185,22 @@ __global__ void __launch_bounds__(64) random_init_kernel(uint32_t npix, uint64_t
     state[5 * (size_t)npix + idx] = r.d;
 }
 
-__global__ void __launch_bounds__(64) render_kernel(RenderArgs a) {
+#ifndef CRT_WAVES_PER_EU
+#define CRT_WAVES_PER_EU 1
+#endif
+__global__ void __launch_bounds__(64, CRT_WAVES_PER_EU) render_kernel(RenderArgs a) {
     ScenePtr sc = (ScenePtr)a.scene;
     const float* __restrict__ ltc = a.ltc;
     const uint32_t lane = threadIdx.x;
     float4* __restrict__ out = reinterpret_cast<float4*>(a.out);
     const uint32_t npix = a.nx * a.ny;
 
-    // deferred glass-shadow work: ray, first hit and the lane that owns the sample
-    __shared__ float q_f[9][kQueueCap];
-    __shared__ uint32_t q_meta[kQueueCap];
-    __shared__ uint32_t s_shadow[64];
+    // stage-2 queues: shadow rays that may hit something, and rays whose closest hit is glass
+    __shared__ float rq_f[7][kRayQueueCap];     // origin, direction, max distance
+    __shared__ uint32_t rq_owner[kRayQueueCap]; // lane that owns the sample
+    __shared__ float gq_f[9][kGlassQueueCap];   // origin, direction, first hit (t,u,v)
+    __shared__ uint32_t gq_meta[kGlassQueueCap]; // primitive | owner << 16
+    __shared__ uint32_t s_shadow[64];           // covered samples found by stage 2, per owner lane
 
     // get_world_coordinates (main.cu:306-314) and pixel_size (main.cu:337): image-wide constants
     const float height_world = 2.0f;
@@ -220,6 +231,10 @@ __global__ void __launch_bounds__(64) render_kernel(RenderArgs a) {
     uint32_t pix = 0, out_index = 0;
     Rng rng = {0, 0, 0, 0, 0, 0};
     uint32_t cnt_shade = 0, cnt_expand = 0;
+    uint32_t w_stage2 = 0, w_glass = 0; // wave-uniform tallies of queued rays
+#ifdef CRT_DEBUG_SHADOW
+    float dbg_shadow = -1.0f;
+#endif
 
     // adaptive-AA task list (aa_color, main.cu:230-304)
     AATask aa_stack[10];
@@ -318,6 +333,10 @@ __global__ void __launch_bounds__(64) render_kernel(RenderArgs a) {
                             // render() epilogue (main.cu:339-346)
                             out[out_index] = make_float4(saturate_c(acc.x), saturate_c(acc.y), saturate_c(acc.z),
                                                          saturate_c(acc.w));
+#ifdef CRT_DEBUG_SHADOW
+                            out[out_index].w = dbg_shadow;
+                            out[out_index].x = acc.x;
+#endif
                             a.rng[0 * (size_t)npix + pix] = rng.v0;
                             a.rng[1 * (size_t)npix + pix] = rng.v1;
                             a.rng[2 * (size_t)npix + pix] = rng.v2;
@@ -537,109 +556,195 @@ __global__ void __launch_bounds__(64) render_kernel(RenderArgs a) {
             const V3 lpos = ld3c(L->pos);
             const V3 lp0 = ld3c(L->p0), lp2 = ld3c(L->p2);
             const V3 le01 = ld3c(L->e01), le03 = ld3c(L->e03), le23 = ld3c(L->e23), le21 = ld3c(L->e21);
-            uint32_t shadowed = 0;
-            uint32_t qcount = 0; // wave-uniform
+            uint32_t shadowed = 0; // stays 0 here: every covered sample is counted by stage 2
+            uint32_t rq = 0, gq = 0; // queue fills, wave-uniform
             s_shadow[lane] = 0u;
-            for (uint32_t s = 0; s < S; ++s) {
-                bool glass = false;
-                V3 so = mk3(0, 0, 0), sd = mk3(0, 0, 0);
-                Hit h;
-                h.idx = -1;
-                h.mat_type = 0;
-                h.t = kFltMax;
-                h.u = h.v = 0.0f;
+            for (uint32_t s = 0; s < S; s += 2u) {
+                const bool two = s + 1u < S; // second sample of this round exists (wave-uniform)
+                bool may0 = false, may1 = false;
+                V3 o0 = mk3(0, 0, 0), d0 = mk3(0, 0, 0), o1 = mk3(0, 0, 0), d1 = mk3(0, 0, 0);
+                float x0 = 0.0f, x1 = 0.0f;
                 if (act) {
-                    float u = rng_uniform(rng);
-                    float v = rng_uniform(rng);
-                    V3 sample; // _randomPoint (AreaLight.hpp:340-375)
-                    if (u + v < 1.0f) {
-                        sample = ((lp0 + le01 * u) + le03 * v) + lpos;
-                    } else {
-                        u = 1.0f - u;
-                        v = 1.0f - v;
-                        sample = ((lp2 + le23 * u) + le21 * v) + lpos;
-                    }
-                    V3 dir = sample - n_P;
-                    float dist = length3(dir);
-                    if (!eps_equal(dist, 0.0f, kEps)) dir = normalize3(dir);
-                    so = n_P + dir * 0.01f;
-                    sd = ray_dir(dir);                      // the Ray ctor normalises once more (Ray.hpp:45-52)
-                    const float maxd = max_std(0.0f, dist); // Ray::setDistance
-                    // first pass of Light::_isCovered (Light.hpp:41-46): closest hit decides
-                    const float dd = dot3(sd, sd);
-                    for (uint32_t i = 0; i < n_geom_all; ++i) {
-                        const DevGeomHot CRT_CONST* g = &sc->hot[i];
-                        const uint32_t kind = g->kind, mat = g->mat_type;
-                        const V3 go = ld3c(g->o), gn = ld3c(g->n);
-                        float t = 0.0f, uu = 0.0f, vv = 0.0f;
-                        bool hit;
-                        if (kind == CRT_GEOM_SPHERE) {
-                            hit = sphere_t(go, gn.x, so, sd, dd, maxd, t);
+                    // ---- stage 1: draw, build the shadow rays, filter against every primitive
+                    {
+                        float u = rng_uniform(rng);
+                        float v = rng_uniform(rng);
+                        V3 sample; // _randomPoint (AreaLight.hpp:340-375)
+                        if (u + v < 1.0f) {
+                            sample = ((lp0 + le01 * u) + le03 * v) + lpos;
                         } else {
-                            V3 p = so - go;
-                            hit = quad_plane_t(p, sd, gn, maxd, h.t, t);
-                            if (hit) {
-                                UVRec q = load_uv(&sc->uv[i]);
-                                hit = quad_uv<false>(q, p, sd, t, uu, vv);
-                            }
+                            u = 1.0f - u;
+                            v = 1.0f - v;
+                            sample = ((lp2 + le23 * u) + le21 * v) + lpos;
                         }
-                        if (hit && !(t > h.t)) {
-                            h.idx = (int)i;
-                            h.mat_type = mat;
-                            h.t = t;
-                            h.u = uu;
-                            h.v = vv;
+                        V3 dir = sample - n_P;
+                        float dist;
+                        V3 ndir = normalize3_len(dir, dist);
+                        if (!eps_equal(dist, 0.0f, kEps)) dir = ndir;
+                        o0 = n_P + dir * 0.01f;
+                        d0 = ray_dir(dir);            // the Ray ctor normalises once more (Ray.hpp:45-52)
+                        x0 = max_std(0.0f, dist);     // Ray::setDistance
+                    }
+                    if (two) {
+                        float u = rng_uniform(rng);
+                        float v = rng_uniform(rng);
+                        V3 sample;
+                        if (u + v < 1.0f) {
+                            sample = ((lp0 + le01 * u) + le03 * v) + lpos;
+                        } else {
+                            u = 1.0f - u;
+                            v = 1.0f - v;
+                            sample = ((lp2 + le23 * u) + le21 * v) + lpos;
                         }
+                        V3 dir = sample - n_P;
+                        float dist;
+                        V3 ndir = normalize3_len(dir, dist);
+                        if (!eps_equal(dist, 0.0f, kEps)) dir = ndir;
+                        o1 = n_P + dir * 0.01f;
+                        d1 = ray_dir(dir);
+                        x1 = max_std(0.0f, dist);
                     }
-                    if (h.idx >= 0) {
-                        if (h.mat_type != CRT_MAT_REFRACTIVE) ++shadowed;
-                        else glass = true;
+                    const float dd0 = dot3(d0, d0), dd1 = dot3(d1, d1);
+                    const float dd40 = 4.0f * dd0, dd41 = 4.0f * dd1; // 4.f * a (Sphere.hpp:61)
+                    const bool ddok0 = dd0 > 1e-6f && dd0 < 1e6f, ddok1 = dd1 > 1e-6f && dd1 < 1e6f;
+                    const bool xok0 = x0 > 1e-30f && x0 < 1e30f, xok1 = x1 > 1e-30f && x1 < 1e30f;
+                    // the record of primitive i+1 is requested before primitive i is tested
+                    const DevGeomHot CRT_CONST* g = &sc->hot[0];
+                    uint32_t kind = g->kind;
+                    V3 go = ld3c(g->o), gn = ld3c(g->n);
+                    for (uint32_t i = 0; i < n_geom_all; ++i) {
+                        const uint32_t ckind = kind;
+                        const V3 cgo = go, cgn = gn;
+                        if (i + 1u < n_geom_all) {
+                            g = &sc->hot[i + 1u];
+                            kind = g->kind;
+                            go = ld3c(g->o);
+                            gn = ld3c(g->n);
+                        }
+                        bool h0, h1;
+                        if (ckind == CRT_GEOM_SPHERE) {
+                            h0 = sphere_may_hit(cgo, cgn.x, o0, d0, dd40, ddok0);
+                            h1 = sphere_may_hit(cgo, cgn.x, o1, d1, dd41, ddok1);
+                        } else if (ckind == CRT_HOT_QUAD_X) {
+                            h0 = plane_may_hit((o0.x - cgo.x) * cgn.x, d0.x * cgn.x, x0, xok0);
+                            h1 = plane_may_hit((o1.x - cgo.x) * cgn.x, d1.x * cgn.x, x1, xok1);
+                        } else if (ckind == CRT_HOT_QUAD_Y) {
+                            h0 = plane_may_hit((o0.y - cgo.y) * cgn.y, d0.y * cgn.y, x0, xok0);
+                            h1 = plane_may_hit((o1.y - cgo.y) * cgn.y, d1.y * cgn.y, x1, xok1);
+                        } else if (ckind == CRT_HOT_QUAD_Z) {
+                            h0 = plane_may_hit((o0.z - cgo.z) * cgn.z, d0.z * cgn.z, x0, xok0);
+                            h1 = plane_may_hit((o1.z - cgo.z) * cgn.z, d1.z * cgn.z, x1, xok1);
+                        } else {
+                            h0 = quad_may_hit(o0 - cgo, d0, cgn, x0, xok0);
+                            h1 = quad_may_hit(o1 - cgo, d1, cgn, x1, xok1);
+                        }
+                        may0 = may0 | h0;
+                        may1 = may1 | h1;
                     }
+                    may1 = may1 && two;
                 }
-                // ---- queue the glass continuation (rare) instead of walking it with 63 lanes idle
-                const uint64_t gm = __ballot(glass);
-                if (gm != 0) {
-                    if (glass) {
-                        const uint32_t slot = qcount + lane_rank(gm);
-                        q_f[0][slot] = so.x;
-                        q_f[1][slot] = so.y;
-                        q_f[2][slot] = so.z;
-                        q_f[3][slot] = sd.x;
-                        q_f[4][slot] = sd.y;
-                        q_f[5][slot] = sd.z;
-                        q_f[6][slot] = h.t;
-                        q_f[7][slot] = h.u;
-                        q_f[8][slot] = h.v;
-                        q_meta[slot] = (uint32_t)h.idx | (lane << 16);
+                // ---- append the surviving rays to the stage-2 queue
+                const uint64_t m0 = __ballot(may0);
+                const uint64_t m1 = __ballot(may1);
+                if ((m0 | m1) != 0) {
+                    if (may0) {
+                        const uint32_t slot = rq + lane_rank(m0);
+                        rq_f[0][slot] = o0.x;
+                        rq_f[1][slot] = o0.y;
+                        rq_f[2][slot] = o0.z;
+                        rq_f[3][slot] = d0.x;
+                        rq_f[4][slot] = d0.y;
+                        rq_f[5][slot] = d0.z;
+                        rq_f[6][slot] = x0;
+                        rq_owner[slot] = lane;
                     }
-                    qcount += (uint32_t)__popcll(gm);
+                    rq += (uint32_t)__popcll(m0);
+                    if (may1) {
+                        const uint32_t slot = rq + lane_rank(m1);
+                        rq_f[0][slot] = o1.x;
+                        rq_f[1][slot] = o1.y;
+                        rq_f[2][slot] = o1.z;
+                        rq_f[3][slot] = d1.x;
+                        rq_f[4][slot] = d1.y;
+                        rq_f[5][slot] = d1.z;
+                        rq_f[6][slot] = x1;
+                        rq_owner[slot] = lane;
+                    }
+                    rq += (uint32_t)__popcll(m1);
+                    w_stage2 += (uint32_t)(__popcll(m0) + __popcll(m1));
                 }
-                const bool last = (s + 1u == S);
-                if (qcount >= 64u || (last && qcount > 0u)) {
+                // ---- stage 2: full batches during the loop, everything after the last round
+                const bool last = s + 2u >= S;
+                while (rq >= 64u || gq >= 64u || (last && (rq | gq) != 0u)) {
                     __syncthreads();
-                    do { // one batch of 64 in mid-loop (fewer than 64 stay queued), everything after the last sample
-                        const uint32_t n = qcount < 64u ? qcount : 64u;
-                        const uint32_t base = qcount - n;
+                    if (gq < 64u && (rq >= 64u || (last && rq != 0u))) { // a full glass batch goes first: its queue must stay below 64
+                        // exact closest hit of Light::_isCovered's first pass (Light.hpp:41-46)
+                        const uint32_t n = rq < 64u ? rq : 64u;
+                        const uint32_t base = rq - n;
+                        bool glass = false;
+                        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
+                        Hit h;
+                        h.idx = -1;
+                        h.mat_type = 0;
+                        h.t = h.u = h.v = 0.0f;
+                        uint32_t owner = 0;
                         if (lane < n) {
                             const uint32_t slot = base + lane;
-                            V3 o = mk3(q_f[0][slot], q_f[1][slot], q_f[2][slot]);
-                            V3 d = mk3(q_f[3][slot], q_f[4][slot], q_f[5][slot]);
+                            o = mk3(rq_f[0][slot], rq_f[1][slot], rq_f[2][slot]);
+                            d = mk3(rq_f[3][slot], rq_f[4][slot], rq_f[5][slot]);
+                            owner = rq_owner[slot];
+                            h = closest_hit(sc, o, d, rq_f[6][slot]);
+                            if (h.idx >= 0) {
+                                if (h.mat_type != CRT_MAT_REFRACTIVE) atomicAdd(&s_shadow[owner], 1u);
+                                else glass = true;
+                            }
+                        }
+                        rq = base;
+                        const uint64_t gm = __ballot(glass);
+                        if (gm != 0) {
+                            if (glass) {
+                                const uint32_t slot = gq + lane_rank(gm);
+                                gq_f[0][slot] = o.x;
+                                gq_f[1][slot] = o.y;
+                                gq_f[2][slot] = o.z;
+                                gq_f[3][slot] = d.x;
+                                gq_f[4][slot] = d.y;
+                                gq_f[5][slot] = d.z;
+                                gq_f[6][slot] = h.t;
+                                gq_f[7][slot] = h.u;
+                                gq_f[8][slot] = h.v;
+                                gq_meta[slot] = (uint32_t)h.idx | (owner << 16);
+                            }
+                            gq += (uint32_t)__popcll(gm);
+                            w_glass += (uint32_t)__popcll(gm);
+                        }
+                    } else {
+                        // refraction walk of Light::_isCovered (Light.hpp:47-80)
+                        const uint32_t n = gq < 64u ? gq : 64u;
+                        const uint32_t base = gq - n;
+                        if (lane < n) {
+                            const uint32_t slot = base + lane;
+                            V3 o = mk3(gq_f[0][slot], gq_f[1][slot], gq_f[2][slot]);
+                            V3 d = mk3(gq_f[3][slot], gq_f[4][slot], gq_f[5][slot]);
                             Hit qh;
-                            const uint32_t meta = q_meta[slot];
+                            const uint32_t meta = gq_meta[slot];
                             qh.idx = (int)(meta & 0xffffu);
                             qh.mat_type = CRT_MAT_REFRACTIVE;
-                            qh.t = q_f[6][slot];
-                            qh.u = q_f[7][slot];
-                            qh.v = q_f[8][slot];
+                            qh.t = gq_f[6][slot];
+                            qh.u = gq_f[7][slot];
+                            qh.v = gq_f[8][slot];
                             if (covered_through_glass(sc, L, o, d, qh)) atomicAdd(&s_shadow[meta >> 16], 1u);
                         }
-                        qcount = base;
-                    } while (last && qcount > 0u);
+                        gq = base;
+                    }
                     __syncthreads();
                 }
             }
             if (act) {
                 shadowed += s_shadow[lane];
+#ifdef CRT_DEBUG_SHADOW
+                dbg_shadow = (float)shadowed;
+#endif
                 float visibility = 1.0f - ((float)shadowed / (float)S);
                 direct = direct + area_light_shade(ltc, L, gs, n_P, n_N, n_view, visibility);
             }
@@ -670,6 +775,10 @@ __global__ void __launch_bounds__(64) render_kernel(RenderArgs a) {
             have_node = false;
         }
     }
+    if (lane == 0 && a.wave_tallies) {
+        atomicAdd(&a.wave_tallies[0], (unsigned long long)w_stage2);
+        atomicAdd(&a.wave_tallies[1], (unsigned long long)w_glass);
+    }
 }
 
 // Scatter of gathered shard buffers into the row-major framebuffer.
@@ -684,7 +793,8 @@ __global__ void __launch_bounds__(64) scatter_kernel(uint32_t nx, uint32_t ny, u
     if (i < nx && j < ny) fb[(size_t)j * nx + i] = gathered[((size_t)rank * tiles_max + k) * 64u + lane];
 }
 
-// Exhaustive check of rcp_exact against the IEEE quotient; bits = blockIdx-strided sweep of all 2^32 patterns.
+// Exhaustive check of the fast correctly-rounded helpers against the IEEE results over all 2^32 bit
+// patterns: rcp_exact vs 1.0f/x everywhere; rcp_nr vs 1.0f/x and sqrt_nr vs sqrtf on [2^-100, 2^100].
 __global__ void __launch_bounds__(256) selftest_rcp_kernel(unsigned long long* __restrict__ mismatches,
                                                            uint32_t* __restrict__ first_bad) {
     unsigned long long bad = 0;
@@ -694,6 +804,11 @@ __global__ void __launch_bounds__(256) selftest_rcp_kernel(unsigned long long* _
         float r = rcp_exact(x);
         float q = 1.0f / x;
         bool same = (__float_as_uint(r) == __float_as_uint(q)) || (r != r && q != q);
+        float ax = __builtin_fabsf(x);
+        if (ax >= 0x1p-100f && ax <= 0x1p100f) {
+            same = same && (__float_as_uint(rcp_nr(x)) == __float_as_uint(q));
+            if (x > 0.0f) same = same && (__float_as_uint(sqrt_nr(x)) == __float_as_uint(__builtin_sqrtf(x)));
+        }
         if (!same) {
             ++bad;
             atomicMin(first_bad, (uint32_t)b);

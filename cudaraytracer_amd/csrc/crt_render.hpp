@@ -19,6 +19,7 @@ struct RenderArgs {
     uint32_t* rng;    // 6 planes of nx*ny words: v0..v4, d
     uint32_t* counters; // 2 planes of nx*ny words: shaded diffuse hits, expanding hits (accumulated)
     float* out;
+    unsigned long long* wave_tallies; // [0] rays sent to stage 2, [1] rays sent to the glass walk (accumulated)
     uint32_t* unit_counter; // global work-unit cursor (zeroed by launch_render)
     uint32_t n_units;       // 64-pixel work units in this launch
     uint32_t nx, ny;

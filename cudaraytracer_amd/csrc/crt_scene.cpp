@@ -155,6 +155,9 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
             QuadConst q = quad_constants(p0, ld(g.v[1].pos), ld(g.v[2].pos), ld(g.v[3].pos));
             st(h.o, p0);
             st(h.n, q.nor);
+            if (q.nor.y == 0.0f && q.nor.z == 0.0f && q.nor.x != 0.0f) h.kind = CRT_HOT_QUAD_X;
+            else if (q.nor.x == 0.0f && q.nor.z == 0.0f && q.nor.y != 0.0f) h.kind = CRT_HOT_QUAD_Y;
+            else if (q.nor.x == 0.0f && q.nor.y == 0.0f && q.nor.z != 0.0f) h.kind = CRT_HOT_QUAD_Z;
             fill_uv(out->uv[i], q);
             for (int k = 0; k < 4; ++k) memcpy(d.n[k], g.v[k].normal, 12);
         }

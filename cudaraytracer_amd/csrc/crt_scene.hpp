@@ -20,14 +20,20 @@
 namespace crt {
 
 // All members are 4-byte so that a wave-uniform index turns into scalar loads.
-struct DevGeomHot {
-    uint32_t kind;     // CRT_GEOM_*
+// DevGeomHot::kind: CRT_GEOM_SPHERE (0), CRT_GEOM_QUAD (1), or a quad whose plane normal has a
+// single non-zero component (the dot products with it collapse to one multiplication).
+#define CRT_HOT_QUAD_X 2u
+#define CRT_HOT_QUAD_Y 3u
+#define CRT_HOT_QUAD_Z 4u
+
+struct alignas(32) DevGeomHot {
+    uint32_t kind;     // CRT_GEOM_SPHERE, CRT_GEOM_QUAD or CRT_HOT_QUAD_X/Y/Z
     uint32_t mat_type; // CRT_MAT_*
     float o[3];        // sphere centre (Sphere.hpp:43) / quad corner v0 (Quad.hpp:202)
     float n[3];        // quad: nor = (v1-v0) x (v3-v0) (Quad.hpp:205-220); sphere: {radius^2, 0, 0} (Sphere.hpp:56)
 };
 
-struct DevGeomUV { // quad only (Quad.hpp:232-250): everything that depends only on the vertices
+struct alignas(16) DevGeomUV { // quad only (Quad.hpp:232-250): everything that depends only on the vertices
     uint32_t idu, idv;         // the two kept axes (lut {1,2,0,1})
     uint32_t linear;           // |k2| < 1e-4 -> linear branch (Quad.hpp:255)
     float nor_id;              // nor[id]
@@ -36,7 +42,7 @@ struct DevGeomUV { // quad only (Quad.hpp:232-250): everything that depends only
     float pad;
 };
 
-struct DevGeomShade {
+struct alignas(16) DevGeomShade {
     float n[4][3];       // quad vertex normals (Quad.hpp:310-325)
     float ambient[4];    // Material::ambient
     float diffuse[4];    // Material::diffuse
@@ -47,7 +53,7 @@ struct DevGeomShade {
     uint32_t pad;
 };
 
-struct DevLight {
+struct alignas(64) DevLight {
     uint32_t kind;
     uint32_t two_sided;
     uint32_t shadow_samples;
@@ -66,7 +72,7 @@ struct DevLight {
     DevGeomUV uv;
 };
 
-struct DevCamera {
+struct alignas(64) DevCamera {
     float pos[3], front[3], right[3], up[3]; // Camera.hpp:97-98
     float one_over_tan;                      // 1 / tan(fov/2) (Camera.hpp:133)
     float ortho_scale;
@@ -74,11 +80,11 @@ struct DevCamera {
     uint32_t pad;
 };
 
-struct DevScene {
+struct alignas(64) DevScene {
     DevCamera cam;
     uint32_t n_geom;
     uint32_t n_lights;
-    uint32_t pad[2];
+    uint32_t pad[14];
     DevGeomHot hot[CRT_MAX_GEOMETRY];
     DevGeomUV uv[CRT_MAX_GEOMETRY];
     DevGeomShade shade[CRT_MAX_GEOMETRY];

@@ -137,6 +137,8 @@ typedef struct crt_stats {
     uint64_t shadow_samples; /* _calculateVisibility samples */
     uint64_t shade_points;   /* AreaLight::calculateColor calls */
     uint64_t gi_children;    /* (r1,r2) pairs drawn at expanding diffuse hits */
+    uint64_t exact_tests;    /* shadow rays that needed the exact closest-hit test (not culled by the filter) */
+    uint64_t glass_walks;    /* shadow rays that entered the refraction walk of Light::_isCovered */
 } crt_stats;
 
 typedef struct crt_ctx crt_ctx;
