@@ -333,6 +333,7 @@ int crt_fb_alloc(crt_ctx* ctx, size_t n_floats, float** out_dev) {
     int rc = bind(ctx);
     if (rc != CRT_OK) return rc;
     HIP_TRY(ctx, hipMalloc((void**)out_dev, n_floats * sizeof(float)));
+    HIP_TRY(ctx, hipMemset(*out_dev, 0, n_floats * sizeof(float))); // pixels a progressive walk never reaches read as 0
     return CRT_OK;
 }
 

@@ -218,6 +218,7 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out);
 int crt_selftest_rcp(crt_ctx* ctx, uint64_t* mismatches, uint32_t* first_bad_bits);
 
 /* ---- device-buffer helpers for hosts without their own allocator -------- */
+/* Allocates and zero-fills n_floats floats of device memory.  Synchronous. */
 int crt_fb_alloc(crt_ctx* ctx, size_t n_floats, float** out_dev);
 int crt_fb_free(crt_ctx* ctx, float* dev);
 /* Synchronous device-to-host copy (the reference reads managed memory, main.cu:816,856). */

@@ -81,6 +81,17 @@ def cornell(shadow_samples=50):
     return Scene(cam, list(geo), list(light))
 
 
+def initial_state(nx, ny, seed):
+    """Per-pixel states as random_init leaves them: curand_init(seed + idx, 0, 0) (main.cu:317-325)."""
+    st = np.zeros((ny * nx, 6), dtype=np.uint32)
+    buf = (C.c_uint32 * 6)()
+    L = lib()
+    for idx in range(nx * ny):
+        L.orc_rng_init(seed + idx, buf)
+        st[idx] = buf[:]
+    return st
+
+
 def render(scene, settings, seed, region=None, rng_state=None, threads=0, want_state=False):
     """Returns (fb[ny,nx,4] float32, counters, rng_state or None)."""
     nx, ny = settings.nx, settings.ny
