@@ -48,7 +48,7 @@ def cpu_baseline(workload_gl, budget_s):
     import oracle_lib as O
     import cudaraytracer_amd as crt
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    crop = {0: 360, 1: 64, 2: 8}[workload_gl]
+    crop = {0: 720, 1: 400, 2: 40}[workload_gl]  # about 10-20 s on 16 host threads
     st = crt.make_settings(gl_iter=workload_gl)
     x0 = (720 - crop) // 2
     sc = O.cornell(50)
@@ -156,7 +156,7 @@ def main():
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get(f"{args.workload}_n{world}_{nx}x{ny}")
+                traffic = json.loads(tfile.read_text()).get(f"{args.workload}_n{world}_{nx}x{ny}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
