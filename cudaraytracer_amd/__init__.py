@@ -56,6 +56,8 @@ def lib():
                                              C.c_void_p]),
             "crt_stats_since_init": (C.c_int, [C.c_void_p, P(abi.crt_settings), P(abi.crt_stats)]),
             "crt_selftest_rcp": (C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint32)]),
+            "crt_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
+            "crt_set_workspace_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
             "crt_fb_alloc": (C.c_int, [C.c_void_p, C.c_size_t, P(C.c_void_p)]),
             "crt_fb_free": (C.c_int, [C.c_void_p, C.c_void_p]),
             "crt_fb_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -73,7 +75,8 @@ def lib():
 ABI_SYMBOLS = (
     "crt_create", "crt_destroy", "crt_last_error", "crt_cornell_scene", "crt_scene_upload", "crt_rng_init",
     "crt_rng_export", "crt_render", "crt_render_partial", "crt_render_shard", "crt_shard_tiles",
-    "crt_shard_tiles_max", "crt_scatter_shards", "crt_stats_since_init", "crt_selftest_rcp", "crt_fb_alloc", "crt_fb_free",
+    "crt_shard_tiles_max", "crt_scatter_shards", "crt_stats_since_init", "crt_selftest_rcp", "crt_set_pipeline",
+    "crt_set_workspace_limit", "crt_fb_alloc", "crt_fb_free",
     "crt_fb_download", "crt_write_hdr", "crt_encode_hdr")
 
 
@@ -161,6 +164,13 @@ class Context:
         s = abi.crt_stats()
         self._check(lib().crt_stats_since_init(self._h, C.byref(settings), C.byref(s)), "crt_stats_since_init")
         return s
+
+    def set_pipeline(self, pipeline):
+        """abi.CRT_PIPELINE_AUTO / _PERSISTENT / _WAVEFRONT."""
+        self._check(lib().crt_set_pipeline(self._h, pipeline), "crt_set_pipeline")
+
+    def set_workspace_limit(self, nbytes):
+        self._check(lib().crt_set_workspace_limit(self._h, nbytes), "crt_set_workspace_limit")
 
     def selftest_rcp(self):
         """(mismatches, first mismatching bit pattern) of the fast reciprocal vs 1.0f/x over all floats."""

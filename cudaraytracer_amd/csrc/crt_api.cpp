@@ -27,6 +27,9 @@ struct crt_ctx {
     uint32_t* counters_dev = nullptr; // 2 planes of npix words: shade points, expansions
     uint32_t* unit_counter = nullptr; // work-unit cursor of the persistent render grid
     uint32_t rng_nx = 0, rng_ny = 0;
+    int pipeline = CRT_PIPELINE_AUTO;
+    size_t workspace_limit = (size_t)32 << 30;
+    crt::WfWorkspace wf;
 };
 
 namespace {
@@ -86,7 +89,27 @@ crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
     a.tiles_x = (st->nx + 7u) / 8u;
     a.tiles_y = (st->ny + 7u) / 8u;
     a.world = 1;
+    for (uint32_t l = 0; l < ctx->scene_host.n_lights; ++l) {
+        const crt::DevLight& L = ctx->scene_host.lights[l];
+        if (L.kind == CRT_LIGHT_AREA && L.initialized) a.max_shadow_rays += L.shadow_samples;
+    }
     return a;
+}
+
+// Runs one launch through the pipeline the context selects.
+int run_render(crt_ctx* ctx, const crt::RenderArgs& a, hipStream_t stream) {
+    const bool can_wf = crt::wavefront_supports(a);
+    if (ctx->pipeline == CRT_PIPELINE_WAVEFRONT && !can_wf)
+        return fail(ctx, CRT_ERR_UNSUPPORTED, "the wavefront pipeline needs aa_iter <= 1 (got %u)", a.aa_iter);
+    if (ctx->pipeline == CRT_PIPELINE_PERSISTENT || !can_wf) {
+        HIP_TRY(ctx, crt::launch_render(a, stream));
+        return CRT_OK;
+    }
+    HIP_TRY(ctx, crt::wavefront_reserve(ctx->wf, a, ctx->scene_host.n_lights, ctx->workspace_limit));
+    bool overflow = false;
+    HIP_TRY(ctx, crt::launch_wavefront(a, ctx->wf, stream, &overflow));
+    if (overflow) return fail(ctx, CRT_ERR_HIP, "wavefront pipeline: a device queue overflowed");
+    return CRT_OK;
 }
 
 } // namespace
@@ -124,6 +147,7 @@ void crt_destroy(crt_ctx* ctx) {
         (void)hipFree(ctx->rng_init_d);
         (void)hipFree(ctx->counters_dev);
         (void)hipFree(ctx->unit_counter);
+        crt::wavefront_release(ctx->wf);
     }
     delete ctx;
 }
@@ -195,8 +219,7 @@ int crt_render(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void* stream
     crt::RenderArgs a = base_args(ctx, st, fb_dev);
     a.mode = crt::MODE_FULL;
     a.n_units = a.tiles_x * a.tiles_y;
-    HIP_TRY(ctx, crt::launch_render(a, (hipStream_t)stream));
-    return CRT_OK;
+    return run_render(ctx, a, (hipStream_t)stream);
 }
 
 int crt_render_partial(crt_ctx* ctx, const crt_settings* st, uint32_t tileIndex, float* fb_dev, void* stream) {
@@ -226,8 +249,7 @@ int crt_render_partial(crt_ctx* ctx, const crt_settings* st, uint32_t tileIndex,
     a.start_by = (tileIndex / blocksX) < blocksY ? (tileIndex / blocksX) : blocksY;
     const uint64_t lanes = (uint64_t)bx * by * st->tx * st->ty;
     a.n_units = (uint32_t)((lanes + 63u) / 64u);
-    HIP_TRY(ctx, crt::launch_render(a, (hipStream_t)stream));
-    return CRT_OK;
+    return run_render(ctx, a, (hipStream_t)stream);
 }
 
 uint32_t crt_shard_tiles(uint32_t nx, uint32_t ny, uint32_t rank, uint32_t world) {
@@ -258,8 +280,7 @@ int crt_render_shard(crt_ctx* ctx, const crt_settings* st, uint32_t rank, uint32
     const uint32_t tiles_max = crt_shard_tiles_max(st->nx, st->ny, world);
     HIP_TRY(ctx, hipMemsetAsync(compact_dev, 0, (size_t)tiles_max * 256u * sizeof(float), (hipStream_t)stream));
     a.n_units = crt_shard_tiles(st->nx, st->ny, rank, world);
-    HIP_TRY(ctx, crt::launch_render(a, (hipStream_t)stream));
-    return CRT_OK;
+    return run_render(ctx, a, (hipStream_t)stream);
 }
 
 int crt_scatter_shards(crt_ctx* ctx, uint32_t nx, uint32_t ny, uint32_t world, const float* gathered_dev,
@@ -301,6 +322,21 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out) {
     HIP_TRY(ctx, hipMemcpy(tallies, ctx->unit_counter + 16, 16, hipMemcpyDeviceToHost));
     out->exact_tests = tallies[0];
     out->glass_walks = tallies[1];
+    return CRT_OK;
+}
+
+int crt_set_pipeline(crt_ctx* ctx, int pipeline) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (pipeline != CRT_PIPELINE_AUTO && pipeline != CRT_PIPELINE_PERSISTENT && pipeline != CRT_PIPELINE_WAVEFRONT)
+        return fail(ctx, CRT_ERR_INVALID, "unknown pipeline %d", pipeline);
+    ctx->pipeline = pipeline;
+    return CRT_OK;
+}
+
+int crt_set_workspace_limit(crt_ctx* ctx, size_t bytes) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (bytes < ((size_t)1 << 20)) return fail(ctx, CRT_ERR_INVALID, "workspace limit below 1 MiB");
+    ctx->workspace_limit = bytes;
     return CRT_OK;
 }
 

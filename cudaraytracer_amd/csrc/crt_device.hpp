@@ -327,6 +327,37 @@ DI bool quad_may_hit(V3 p, V3 d, V3 nor, float dist, bool dist_ok) {
     return plane_may_hit(pn, dn, dist, dist_ok);
 }
 
+// Three-way classification of a sphere for a shadow ray: 0 = the reference's test certainly fails,
+// 2 = it certainly succeeds, 1 = undecided (run the exact test).  "Certainly succeeds" (Sphere.hpp:48-96):
+// origin outside (c > 0), approaching (b < 0), discriminant well clear of both the negative early-out and
+// the |discr| < 1e-4 double-root branch; then q = -0.5(b - sqrt(discr)) >= |b|/2 > 0, both roots q/a and
+// c/q are positive and the smaller is at most c/q <= 2c/|b|, which the last condition keeps below `dist`
+// with a margin of 1e-3 against rounding of a few 1e-7.
+DI uint32_t sphere_class(V3 center, float radius_sq, V3 o, V3 d, float dd4, bool dd_ok, float dist) {
+    V3 L = o - center;
+    float b = 2.0f * (d.x * L.x + d.y * L.y + d.z * L.z);
+    float c = (L.x * L.x + L.y * L.y + L.z * L.z) - radius_sq;
+    float bb = b * b, ac4 = dd4 * c;
+    float discr = bb - ac4;
+    bool behind = dd_ok && b > 1e-30f && b < 1e6f && c > 1e-30f && c < 1e6f;
+    if (discr < 0.0f || behind) return 0u;
+    bool sure = dd_ok && c > 1e-4f && c < 1e6f && b < -1e-4f && b > -1e6f &&
+                discr > 2e-4f + 1e-4f * (bb + __builtin_fabsf(ac4)) && dist < 1e6f &&
+                (2.0f * c) < ((-b) * dist) * 0.999f;
+    return sure ? 2u : 1u;
+}
+
+// Conservative use of a quad's bounding box (DevGeomBox): returns false only when the point where the
+// ray meets the plane, o - (pn/dn) d, is certainly outside the box on some axis.  The comparison is
+// multiplied through by |dn|, so nothing is divided; lo/hi already contain the safety margin.
+DI bool box_may_hit(V3 lo, V3 hi, float min_adn, V3 o, V3 d, float pn, float dn) {
+    const float a = __builtin_fabsf(dn);
+    const float sg = dn < 0.0f ? -1.0f : 1.0f;
+    const float qx = (o.x * dn - pn * d.x) * sg, qy = (o.y * dn - pn * d.y) * sg, qz = (o.z * dn - pn * d.z) * sg;
+    const bool outside = qx < lo.x * a || qx > hi.x * a || qy < lo.y * a || qy > hi.y * a || qz < lo.z * a || qz > hi.z * a;
+    return !(a > min_adn && outside);
+}
+
 // Bilinear part of the quad test (Quad.hpp:228-295; AreaLight.hpp:406-480 with
 // LIGHT, whose only difference is 0.5f * (1/k2), AreaLight.hpp:456).
 // p = ray origin relative to corner 0, tt = accepted plane distance.

@@ -28,7 +28,47 @@ struct RenderArgs {
     uint32_t tiles_x, tiles_y; // 8x8 tiles
     uint32_t rank, world;      // MODE_SHARD
     uint32_t tx, ty, blocks_x, blocks_y, win_bx, win_by, start_bx, start_by; // MODE_PARTIAL
+    uint32_t max_shadow_rays; // shadow rays one diffuse hit casts: sum of shadowSamples over initialised area lights
 };
+
+// ---- wavefront pipeline (crt_wavefront.hip)
+// Device workspace of the multi-kernel pipeline; all planes are structure-of-arrays.
+struct WfWorkspace {
+    uint32_t n_lp = 0;      // pixel slots (work units * 64) the planes are sized for
+    uint32_t quota = 0;     // result slots a pixel may fill per round
+    uint32_t gl_levels = 0; // frame levels allocated
+    uint32_t cap_work = 0;  // shade records per round
+    uint32_t n_lights = 0;  // shadow-count planes
+    uint32_t qcap = 0;      // unresolved shadow rays per filter batch
+    uint32_t* ctrs = nullptr;       // device counters (WF_CTR_*), 64 words
+    uint32_t* ctrs_host = nullptr;  // pinned mirror
+    uint32_t* state = nullptr;      // [WF_STATE_PLANES][n_lp] traversal state between rounds
+    uint32_t* frames = nullptr;     // [gl_levels][WF_FRAME_PLANES][n_lp]
+    uint8_t* tags = nullptr;        // [quota][n_lp]
+    float* contrib = nullptr;       // [quota][n_lp] float4
+    uint32_t* slot_count = nullptr; // [n_lp]
+    float* px_acc = nullptr;        // [2][n_lp] float4: colour of the running color() call, pixel accumulator
+    uint32_t* work = nullptr;       // [WF_WORK_PLANES][cap_work]
+    uint32_t* shadow_cnt = nullptr; // [n_lights][cap_work]
+    uint32_t* queue = nullptr;      // [3][qcap]
+    uint32_t* qcounts = nullptr;    // entries per filter wave
+    size_t bytes = 0;
+};
+constexpr uint32_t WF_STATE_PLANES = 17, WF_FRAME_PLANES = 19, WF_WORK_PLANES = 21;
+enum WfCounter : uint32_t {
+    WF_CTR_WORK = 0,    // shade records emitted this round
+    WF_CTR_ACTIVE = 1,  // pixels not finished after this round
+    WF_CTR_ERROR = 5,   // non-zero: a capacity was exceeded (results invalid)
+    WF_CTR_COUNT = 16,
+};
+// True when the wavefront pipeline implements these settings (aa_iter <= 1: no colour-dependent control flow).
+bool wavefront_supports(const RenderArgs& args);
+// Frees / (re)allocates the workspace for this launch; returns hipSuccess or the allocation error.
+hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n_lights, size_t budget_bytes);
+void wavefront_release(WfWorkspace& ws);
+// Runs the pipeline on `stream`; synchronises the stream once per round.  *overflow is set when a
+// capacity check on the device failed.
+hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow);
 
 void launch_random_init(uint32_t npix, uint64_t seed, uint32_t* state, hipStream_t stream);
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream);

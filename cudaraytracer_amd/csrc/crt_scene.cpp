@@ -198,6 +198,88 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
             fill_uv(d.uv, q);
         }
     }
+
+    // Per (light, quad) culling constants.  Along a shadow ray from P (+0.01 along the ray) to a light
+    // sample X (+0.01 beyond it) the signed plane distance s(.) = nor.(. - v0) is linear, so if P and all
+    // of the light are on one side, the plane is crossed neither before the origin nor before the end:
+    // the reference's t = -(p.nor / d.nor) is then negative or exceeds the ray's length (Quad.hpp:222-226).
+    // Margins: `need` keeps the overshoot of 0.01 plus 1e-3 of the scene size between the light and the
+    // plane, which is 500x the rounding of t; `thr` lets P sit on the plane itself (its own quad) as long
+    // as the 0.01 step along the ray certainly lifts the origin off it (noise: rounding of p.nor).
+    double rabs = 0.0;
+    auto grow = [&](double v) { if (fabs(v) > rabs) rabs = fabs(v); };
+    for (uint32_t i = 0; i < in->n_geometry; ++i) {
+        const crt_geometry& g = in->geometry[i];
+        if (g.kind == CRT_GEOM_SPHERE) {
+            for (int k = 0; k < 3; ++k) grow(fabs((double)g.center[k]) + fabs((double)g.radius));
+        } else {
+            for (int v = 0; v < 4; ++v)
+                for (int k = 0; k < 3; ++k) grow(g.v[v].pos[k]);
+        }
+    }
+    for (uint32_t l = 0; l < in->n_lights; ++l)
+        if (in->lights[l].kind == CRT_LIGHT_AREA)
+            for (int v = 0; v < 4; ++v)
+                for (int k = 0; k < 3; ++k) grow(out->lights[l].pts[v][k]);
+    for (uint32_t i = 0; i < CRT_MAX_GEOMETRY; ++i) {
+        DevGeomBox& b = out->box[i];
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] = -INFINITY;
+            b.hi[k] = INFINITY;
+        }
+        b.min_adn = INFINITY;
+        b.pad = 0.0f;
+        if (i >= in->n_geometry || in->geometry[i].kind != CRT_GEOM_QUAD || !out->uv[i].linear) continue;
+        if (!(rabs > 0.0) || !(rabs < 1e6)) continue;
+        const DevGeomHot& h = out->hot[i];
+        const double nlen = sqrt((double)h.n[0] * h.n[0] + (double)h.n[1] * h.n[1] + (double)h.n[2] * h.n[2]);
+        if (!(nlen > 1e-12) || !(nlen < 1e12)) continue;
+        const double margin = 1e-3 * rabs;
+        const uint32_t keep[2] = {out->uv[i].idu, out->uv[i].idv};
+        for (int a = 0; a < 2; ++a) {
+            const uint32_t k = keep[a];
+            double lo = INFINITY, hi = -INFINITY;
+            for (int v = 0; v < 4; ++v) {
+                lo = fmin(lo, (double)in->geometry[i].v[v].pos[k]);
+                hi = fmax(hi, (double)in->geometry[i].v[v].pos[k]);
+            }
+            b.lo[k] = (float)(lo - margin);
+            b.hi[k] = (float)(hi + margin);
+        }
+        b.min_adn = (float)(0.01 * nlen);
+    }
+    const double dmax = 3.5 * rabs; // > 2*sqrt(3)*rabs: no two scene points are further apart
+    for (uint32_t l = 0; l < CRT_MAX_LIGHTS; ++l)
+        for (uint32_t i = 0; i < CRT_MAX_GEOMETRY; ++i) {
+            out->cull_side[l][i] = 0.0f;
+            out->cull_thr[l][i] = INFINITY;
+        }
+    for (uint32_t l = 0; l < in->n_lights; ++l) {
+        if (in->lights[l].kind != CRT_LIGHT_AREA) continue;
+        for (uint32_t i = 0; i < in->n_geometry; ++i) {
+            const DevGeomHot& h = out->hot[i];
+            if (h.kind == CRT_GEOM_SPHERE) continue;
+            const double nlen = sqrt((double)h.n[0] * h.n[0] + (double)h.n[1] * h.n[1] + (double)h.n[2] * h.n[2]);
+            if (!(nlen > 1e-12) || !(nlen < 1e12) || !(rabs > 0.0) || !(rabs < 1e6)) continue;
+            double smin = INFINITY, smax = -INFINITY;
+            for (int v = 0; v < 4; ++v) {
+                double sv = 0.0;
+                for (int k = 0; k < 3; ++k) sv += (double)h.n[k] * ((double)out->lights[l].pts[v][k] - (double)h.o[k]);
+                smin = fmin(smin, sv);
+                smax = fmax(smax, sv);
+            }
+            const double need = nlen * (0.01 + 1e-3 * rabs) * 1.01;
+            double side = 0.0, near = 0.0;
+            if (smin > need) { side = 1.0; near = smin; }
+            else if (smax < -need) { side = -1.0; near = -smax; }
+            else continue;
+            const double noise = 1e-5 * nlen * rabs;
+            const double theta = 0.5 * 0.01 * near / dmax - noise; // P may be this far on the wrong side of the plane
+            out->cull_side[l][i] = (float)side;
+            out->cull_thr[l][i] = (float)(-theta) + (theta < 0 ? 1e-30f : 0.0f);
+            if ((double)out->cull_thr[l][i] < -theta) out->cull_thr[l][i] = nextafterf(out->cull_thr[l][i], INFINITY);
+        }
+    }
     return CRT_OK;
 }
 

@@ -42,6 +42,16 @@ struct alignas(16) DevGeomUV { // quad only (Quad.hpp:232-250): everything that 
     float pad;
 };
 
+// Bounding box of a parallelogram quad, used only to reject: a plane hit whose point lies outside
+// [lo, hi] (already widened by 1e-3 of the scene size) on an axis the reference keeps for its (u,v)
+// solve (Quad.hpp:232-250) cannot yield 0 <= u,v <= 1.  The dropped axis and every axis of a sphere or
+// of a non-parallelogram quad carry -inf/+inf, which never reject.
+struct alignas(32) DevGeomBox {
+    float lo[3], hi[3];
+    float min_adn; // the box test is used only when |d . nor| exceeds this (0.01 |nor|: not grazing)
+    float pad;
+};
+
 struct alignas(16) DevGeomShade {
     float n[4][3];       // quad vertex normals (Quad.hpp:310-325)
     float ambient[4];    // Material::ambient
@@ -88,7 +98,15 @@ struct alignas(64) DevScene {
     DevGeomHot hot[CRT_MAX_GEOMETRY];
     DevGeomUV uv[CRT_MAX_GEOMETRY];
     DevGeomShade shade[CRT_MAX_GEOMETRY];
+    DevGeomBox box[CRT_MAX_GEOMETRY];
     DevLight lights[CRT_MAX_LIGHTS];
+    // Shadow-ray culling of quad `g` for area light `l`, decided once per shaded point P: with
+    // s = nor . (P - v0), the quad cannot stop any shadow ray from P towards that light when
+    // s * cull_side[l][g] > cull_thr[l][g] (the whole light lies on that side of the quad's plane,
+    // further than the 0.01 the ray overshoots, and P is on the same side or on the plane itself).
+    // cull_thr = +inf where no such statement holds (spheres, quads the light straddles or touches).
+    float cull_side[CRT_MAX_LIGHTS][CRT_MAX_GEOMETRY];
+    float cull_thr[CRT_MAX_LIGHTS][CRT_MAX_GEOMETRY];
 };
 
 // Returns CRT_OK or CRT_ERR_INVALID (message in err, if non-null).

@@ -1,0 +1,956 @@
+// Wavefront form of the per-pixel render path for gfx950
+// (render -> aa_color -> color -> GeometryList::hit / AreaLight::calculateColor, main.cu:110-347).
+//
+// The reference walks each pixel's sample tree depth-first inside one thread.  Its control flow
+// (which rays exist, which generator draws they use) does not depend on any shading result as long
+// as aa_iter <= 1, and colours are only ever *added*, in tree order.  The work is therefore split
+// into five dense kernels that hand records to each other through HBM:
+//
+//   trace    one lane per pixel walks the tree (camera rays, mirror/glass bounces, GI children) with
+//            the pixel's XORWOW stream, but shades nothing: every diffuse hit becomes a shade record
+//            {P, N, view, attenuation, primitive, generator state, result slot} and the generator is
+//            stepped past the 2*shadowSamples draws the hit will consume.  Misses write their
+//            (attenuation x black) term straight into their result slot.  A pixel fills at most
+//            `quota` slots per round and keeps its traversal state in HBM between rounds.
+//   filter   one lane per shade record draws the light samples and classifies every shadow ray with
+//            division-free tests against the primitives that survive a per-record cull: certainly
+//            free, certainly blocked by an opaque primitive, or undecided.  Undecided rays (a few per
+//            cent) are compacted through LDS into a queue.
+//   resolve  one lane per queued ray runs the reference's exact closest-hit test and, for glass, the
+//            refraction walk of Light::_isCovered.
+//   shade    one lane per shade record evaluates the two LTC integrals with the final visibility and
+//            writes attenuation x colour into the record's result slot.
+//   sum      one lane per pixel adds its slots in tree order, folds finished color() calls into the
+//            pixel (aa_color's weights) and writes finished pixels.
+//
+// Every kernel runs with all 64 lanes busy on identical work, needs few registers (many waves per
+// SIMD), and the sample tree, the draw order and every floating-point operation stay those of the
+// reference, so results are bit-identical to the single-kernel path in crt_render.hip.
+#include <hip/hip_runtime.h>
+
+#include "crt_device.hpp"
+#include "crt_render.hpp"
+#include "crt_shade.hpp"
+
+namespace crt {
+
+namespace {
+
+enum : uint32_t { TAG_ADD = 0, TAG_END_CALL = 1, TAG_END_PIXEL = 2 };
+constexpr uint32_t kWorkChunk = 256;         // shade-record indices a trace wave reserves at a time
+constexpr uint32_t kMaxFilterWaves = 16384;   // upper bound of the filter kernel's grid
+constexpr uint32_t kNoRecord = 0xffffffffu;  // primitive index of an unused record slot
+
+// state planes
+enum : uint32_t {
+    ST_CTL = 0,   // bit0 done, bit1 color_active, bit2 cur_valid, bits 4..7 call, bits 8..11 nframes
+    ST_CUR_O = 1, ST_CUR_D = 4, ST_CUR_ATT = 7, ST_CUR_REF = 11, ST_CUR_DEPTH = 12, ST_RAY_D = 13, ST_ON_STACK = 16,
+};
+// frame planes
+enum : uint32_t { FR_P = 0, FR_N = 3, FR_ATT = 6, FR_RNG = 10, FR_GEOM = 16, FR_REMAINING = 17, FR_CHILD_DEPTH = 18 };
+// work planes
+enum : uint32_t { WK_P = 0, WK_N = 3, WK_V = 6, WK_ATT = 9, WK_GEOM = 13, WK_RNG = 14, WK_SLOT = 20 };
+
+struct WfArgs {
+    RenderArgs r;
+    uint32_t n_lp, quota, cap_work, qcap;
+    uint32_t* ctrs;
+    uint32_t* state;
+    uint32_t* frames;
+    uint8_t* tags;
+    float4* contrib;
+    uint32_t* slot_count;
+    float4* px_acc;
+    uint32_t* work;
+    uint32_t* shadow_cnt;
+    uint32_t* queue;
+    uint32_t* qcounts;    // entries each filter wave left in its region of the queue
+    uint32_t region_cap;  // queue entries per filter wave
+};
+
+DI float u2f(uint32_t x) { return __uint_as_float(x); }
+DI uint32_t f2u(float x) { return __float_as_uint(x); }
+
+// ---------------------------------------------------------------------------------------- trace
+__global__ void __launch_bounds__(64, 4) wf_trace_kernel(WfArgs w, uint32_t first) {
+    const RenderArgs& a = w.r;
+    ScenePtr sc = (ScenePtr)a.scene;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t unit = blockIdx.x;
+    const size_t n_lp = w.n_lp;
+    const size_t lp = (size_t)unit * 64u + lane;
+    const uint32_t npix = a.nx * a.ny;
+    const PixelMap pm = map_pixel(a, unit, lane);
+    const uint32_t pix = pm.valid ? pm.j * a.nx + pm.i : 0u;
+
+    // get_world_coordinates (main.cu:306-314) and pixel_size (main.cu:337)
+    const float height_world = 2.0f;
+    const float width_world = height_world * ((float)a.nx / (float)a.ny);
+    const float pix_w = width_world / (float)a.nx, pix_h = height_world / (float)a.ny;
+    // Camera::getRay constants (Camera.hpp:97-98,133-134)
+    const V3 cam_pos = ld3c(sc->cam.pos), cam_front = ld3c(sc->cam.front), cam_right = ld3c(sc->cam.right),
+             cam_up = ld3c(sc->cam.up);
+    const V3 eye = cam_pos - cam_front * (width_world * 0.5f * sc->cam.one_over_tan);
+    const uint32_t cam_type = sc->cam.type;
+    float ortho;
+    {
+        float aspect = height_world / width_world;
+        ortho = sc->cam.ortho_scale * (aspect > 1.0f ? aspect : 1.0f);
+    }
+    const uint32_t aa_iter = a.aa_iter;                // 0 or 1 here
+    const uint32_t n_calls = aa_iter == 0u ? 1u : 4u;  // color() calls per pixel (main.cu:254-268)
+    const float inv_ind = 1.0f / (float)a.ind_rays;    // main.cu:182
+    // generator draws one diffuse hit consumes in LightList::calculateColor (AreaLight.hpp:342-343,495)
+    uint32_t skip_draws = 0;
+    for (uint32_t li = 0; li < sc->n_lights; ++li) {
+        const DevLight CRT_CONST* L = &sc->lights[li];
+        if (L->kind == CRT_LIGHT_AREA && L->initialized) skip_draws += 2u * L->shadow_samples;
+    }
+
+    // ---- traversal state
+    uint32_t ctl = 0;
+    if (!first) ctl = w.state[ST_CTL * n_lp + lp];
+    bool done = !pm.valid || (ctl & 1u);
+    const bool live_at_entry = !done;
+    bool color_active = (ctl >> 1) & 1u, cur_valid = (ctl >> 2) & 1u;
+    uint32_t call = (ctl >> 4) & 15u, nframes = (ctl >> 8) & 15u;
+    Rng rng = {0, 0, 0, 0, 0, 0};
+    V3 cur_o = mk3(0, 0, 0), cur_d = mk3(0, 0, 0), ray_d = mk3(0.0f, 0.0f, -1.0f);
+    V4 cur_att = V4{1, 1, 1, 1};
+    uint32_t cur_ref = 0, cur_depth = 0, on_stack = 0;
+    if (live_at_entry) {
+        rng.v0 = a.rng[0 * (size_t)npix + pix];
+        rng.v1 = a.rng[1 * (size_t)npix + pix];
+        rng.v2 = a.rng[2 * (size_t)npix + pix];
+        rng.v3 = a.rng[3 * (size_t)npix + pix];
+        rng.v4 = a.rng[4 * (size_t)npix + pix];
+        rng.d = a.rng[5 * (size_t)npix + pix];
+        if (!first) {
+            const uint32_t* s = w.state + lp;
+            cur_o = mk3(u2f(s[(ST_CUR_O + 0) * n_lp]), u2f(s[(ST_CUR_O + 1) * n_lp]), u2f(s[(ST_CUR_O + 2) * n_lp]));
+            cur_d = mk3(u2f(s[(ST_CUR_D + 0) * n_lp]), u2f(s[(ST_CUR_D + 1) * n_lp]), u2f(s[(ST_CUR_D + 2) * n_lp]));
+            cur_att = V4{u2f(s[(ST_CUR_ATT + 0) * n_lp]), u2f(s[(ST_CUR_ATT + 1) * n_lp]),
+                         u2f(s[(ST_CUR_ATT + 2) * n_lp]), u2f(s[(ST_CUR_ATT + 3) * n_lp])};
+            cur_ref = s[ST_CUR_REF * n_lp];
+            cur_depth = s[ST_CUR_DEPTH * n_lp];
+            ray_d = mk3(u2f(s[(ST_RAY_D + 0) * n_lp]), u2f(s[(ST_RAY_D + 1) * n_lp]), u2f(s[(ST_RAY_D + 2) * n_lp]));
+            on_stack = s[ST_ON_STACK * n_lp];
+        }
+    }
+    // remap<float,true> (math_functions.hpp:31-45)
+    float x_world, y_world;
+    {
+        float denom = (float)a.nx - 0.0f;
+        float es = -width_world * 0.5f, ee = width_world * 0.5f;
+        x_world = (denom == 0.0f) ? (float)pm.i : es + ((ee - es) / denom) * ((float)pm.i - 0.0f);
+        float denomy = (float)a.ny - 0.0f;
+        y_world = (denomy == 0.0f) ? (float)pm.j : 1.0f + ((-1.0f - 1.0f) / denomy) * ((float)pm.j - 0.0f);
+    }
+
+    uint32_t cnt = 0; // result slots filled this round
+    uint32_t cnt_shade = 0, cnt_expand = 0;
+    const uint32_t quota = w.quota;
+    // Shade records are handed out to the wave in chunks of kWorkChunk consecutive indices, so the one
+    // global counter sees one atomic per chunk instead of one per step.
+    uint32_t chunk_base = 0, chunk_used = kWorkChunk; // wave-uniform
+    bool have_chunk = false;
+
+    for (;;) {
+        const bool go = !done && cnt < quota;
+        if (!__any(go)) break;
+        bool emit = false; // a diffuse hit to record
+        V3 n_P = mk3(0, 0, 0), n_N = mk3(0, 0, 0), n_view = mk3(0, 0, 0);
+        V4 n_att = V4{0, 0, 0, 0};
+        uint32_t n_geom = 0, n_depth = 0;
+        if (go) {
+            if (!cur_valid) {
+                if (!color_active) {
+                    if (call == n_calls) {
+                        // render() epilogue (main.cu:339-346) happens in the sum kernel
+                        w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_END_PIXEL;
+                        ++cnt;
+                        done = true;
+                    } else {
+                        // aa_color (main.cu:230-304): level-0 task = pixel centre, level-1 task = 4 corners
+                        float rx, ry;
+                        if (aa_iter == 0u) {
+                            rx = x_world;
+                            ry = y_world;
+                        } else {
+                            float hx = pix_w * 0.5f, hy = pix_h * 0.5f;
+                            float ox = (call & 1u) ? 1.0f : -1.0f, oy = (call & 2u) ? 1.0f : -1.0f;
+                            rx = x_world + ox * hx * 0.5f;
+                            ry = y_world + oy * hy * 0.5f;
+                        }
+                        // Camera::getRay (Camera.hpp:86-144)
+                        V3 ro, rd;
+                        if (cam_type == CRT_CAM_ORTHOGRAPHIC) {
+                            ro = ((cam_right * rx) * ortho + (cam_up * ry) * ortho) + cam_pos;
+                            rd = ray_dir(cam_front);
+                        } else {
+                            ro = (cam_right * rx + cam_up * ry) + cam_pos;
+                            rd = ray_dir(ro - eye);
+                        }
+                        cur_o = ro;
+                        cur_d = rd;
+                        cur_att = V4{1.0f, 1.0f, 1.0f, 1.0f};
+                        cur_ref = a.ref_iter;
+                        cur_depth = a.gl_iter;
+                        cur_valid = true;
+                        color_active = true;
+                        ray_d = mk3(0.0f, 0.0f, -1.0f);
+                        nframes = 0;
+                        on_stack = 0;
+                    }
+                } else if (nframes == 0) {
+                    // color() returned (main.cu:225): the sum kernel folds it into the pixel
+                    w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_END_CALL;
+                    ++cnt;
+                    color_active = false;
+                    ++call;
+                } else {
+                    // pop the next child of the innermost frame (children leave last-to-first)
+                    uint32_t* f = w.frames + ((size_t)(nframes - 1u) * WF_FRAME_PLANES) * n_lp + lp;
+                    Rng rv;
+                    rv.v0 = f[(FR_RNG + 0) * n_lp];
+                    rv.v1 = f[(FR_RNG + 1) * n_lp];
+                    rv.v2 = f[(FR_RNG + 2) * n_lp];
+                    rv.v3 = f[(FR_RNG + 3) * n_lp];
+                    rv.v4 = f[(FR_RNG + 4) * n_lp];
+                    rv.d = f[(FR_RNG + 5) * n_lp];
+                    float r2 = rng_current_uniform(rv);
+                    rng_unstep(rv);
+                    float r1 = rng_current_uniform(rv);
+                    rng_unstep(rv);
+                    V3 hp = mk3(u2f(f[(FR_P + 0) * n_lp]), u2f(f[(FR_P + 1) * n_lp]), u2f(f[(FR_P + 2) * n_lp]));
+                    V3 hn = mk3(u2f(f[(FR_N + 0) * n_lp]), u2f(f[(FR_N + 1) * n_lp]), u2f(f[(FR_N + 2) * n_lp]));
+                    V4 patt = V4{u2f(f[(FR_ATT + 0) * n_lp]), u2f(f[(FR_ATT + 1) * n_lp]), u2f(f[(FR_ATT + 2) * n_lp]),
+                                 u2f(f[(FR_ATT + 3) * n_lp])};
+                    const uint32_t fgeom = f[FR_GEOM * n_lp];
+                    V4 pdiff = ld4c(sc->shade[fgeom].diffuse);
+                    const uint32_t cdepth = f[FR_CHILD_DEPTH * n_lp];
+                    uint32_t rem = f[FR_REMAINING * n_lp] - 1u;
+                    if (rem == 0u) {
+                        --nframes;
+                    } else {
+                        f[FR_REMAINING * n_lp] = rem;
+                        f[(FR_RNG + 0) * n_lp] = rv.v0;
+                        f[(FR_RNG + 1) * n_lp] = rv.v1;
+                        f[(FR_RNG + 2) * n_lp] = rv.v2;
+                        f[(FR_RNG + 3) * n_lp] = rv.v3;
+                        f[(FR_RNG + 4) * n_lp] = rv.v4;
+                        f[(FR_RNG + 5) * n_lp] = rv.d;
+                    }
+                    --on_stack;
+                    // get_random_ray_values_in_hemisphere (main.cu:60-74)
+                    V3 Nx, Nz;
+                    surface_frame(hn, Nx, Nz);
+                    const float PI_2 = 6.28318530717958647692f;
+                    float sinTheta = 1.0f - r1 * r1;
+                    float phi = r2 * PI_2;
+                    float sp, cp;
+                    sincos_c(phi, sp, cp);
+                    float x = sinTheta * cp, z = sinTheta * sp;
+                    V3 wd = mk3(x * Nz.x + r1 * hn.x + z * Nx.x, x * Nz.y + r1 * hn.y + z * Nx.y,
+                                x * Nz.z + r1 * hn.z + z * Nx.z);
+                    cur_o = hp + wd * 0.01f;
+                    cur_d = wd;
+                    cur_att = ((pdiff * (2.0f * r1)) * patt) * inv_ind; // main.cu:186
+                    cur_ref = a.ref_iter;
+                    cur_depth = cdepth;
+                    cur_valid = true;
+                }
+            }
+            if (cur_valid) {
+                // ---- pop (main.cu:132-147)
+                cur_valid = false;
+                if (cur_ref != 0u) {
+                    if (!eps_equal(len_sq(cur_d), 0.0f, kEpsSq)) ray_d = normalize3(cur_d);
+                    const V3 ro = cur_o;
+                    Hit h = closest_hit(sc, ro, ray_d, 0.0f);
+                    if (h.idx < 0) {
+                        // final_color += attenuation * Color::black() (main.cu:149-151)
+                        const V4 c = cur_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
+                        w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_ADD;
+                        w.contrib[(size_t)cnt * n_lp + lp] = make_float4(c.x, c.y, c.z, c.w);
+                        ++cnt;
+                    } else {
+                        V3 P, N;
+                        hit_point_normal(sc, h, ro, ray_d, P, N);
+                        if (h.mat_type == CRT_MAT_DIFFUSE) {
+                            emit = true;
+                            n_P = P;
+                            n_N = N;
+                            n_view = neg(cur_d); // viewDir = -state.r_dir, the stored (un-normalised) direction
+                            n_att = cur_att;
+                            n_geom = (uint32_t)h.idx;
+                            n_depth = cur_depth;
+                        } else if (h.mat_type == CRT_MAT_REFLECT) {
+                            // get_reflect_ray (main.cu:76-81)
+                            V3 I = normalize3(ray_d);
+                            V3 rdir = reflect3(I, normalize3(N));
+                            cur_o = P + rdir * 0.01f;
+                            cur_d = rdir;
+                            cur_att = cur_att * ld4c(sc->shade[h.idx].diffuse);
+                            cur_ref = cur_ref - 1u;
+                            cur_valid = true;
+                        } else {
+                            // get_refraction_ray (main.cu:83-108)
+                            bool front_face = dot3(ray_d, N) < 0.0f;
+                            V3 norm = front_face ? N : neg(N);
+                            float ratio = sc->shade[h.idx].refract_index / 1.0f;
+                            if (front_face) ratio = rcp_exact(ratio);
+                            V3 rdn = normalize3(ray_d);
+                            float cos_theta = __builtin_fminf(dot3(neg(rdn), norm), 1.0f);
+                            float sin_theta = rcp_exact(rsqrt_c(1.0f - cos_theta * cos_theta));
+                            bool cannot_refract = ratio * sin_theta > 1.0f; // reflectance(...) > 1 never holds
+                            V3 dir = cannot_refract ? reflect3(rdn, norm) : refract3(rdn, norm, ratio);
+                            cur_o = P + dir * 0.01f;
+                            cur_d = dir;
+                            cur_att = cur_att * ld4c(sc->shade[h.idx].diffuse);
+                            cur_ref = cur_ref - 1u;
+                            cur_valid = true;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- record the diffuse hits of this step (all lanes are here together)
+        const uint64_t em = __ballot(emit);
+        if (em != 0) {
+            const uint32_t n_emit = (uint32_t)__popcll(em);
+            const bool need_chunk = chunk_used + n_emit > kWorkChunk;
+            uint32_t new_base = 0;
+            if (need_chunk) {
+                if (lane == (uint32_t)__builtin_ctzll(em)) new_base = atomicAdd(&w.ctrs[WF_CTR_WORK], kWorkChunk);
+                new_base = (uint32_t)__builtin_amdgcn_readlane((int)new_base, __builtin_ctzll(em));
+            }
+            const uint32_t my_pos = chunk_used + lane_rank(em);
+            const uint32_t my_wi = my_pos < kWorkChunk ? chunk_base + my_pos : new_base + (my_pos - kWorkChunk);
+            if (need_chunk) {
+                chunk_base = new_base;
+                chunk_used = chunk_used + n_emit - kWorkChunk;
+                have_chunk = true;
+            } else {
+                chunk_used += n_emit;
+            }
+            if (emit) {
+                const uint32_t wi = my_wi;
+                const uint32_t slot_k = cnt;
+                w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_ADD;
+                ++cnt;
+                ++cnt_shade;
+                if (wi < w.cap_work) {
+                    uint32_t* r = w.work + wi;
+                    const size_t cw = w.cap_work;
+                    r[(WK_P + 0) * cw] = f2u(n_P.x);
+                    r[(WK_P + 1) * cw] = f2u(n_P.y);
+                    r[(WK_P + 2) * cw] = f2u(n_P.z);
+                    r[(WK_N + 0) * cw] = f2u(n_N.x);
+                    r[(WK_N + 1) * cw] = f2u(n_N.y);
+                    r[(WK_N + 2) * cw] = f2u(n_N.z);
+                    r[(WK_V + 0) * cw] = f2u(n_view.x);
+                    r[(WK_V + 1) * cw] = f2u(n_view.y);
+                    r[(WK_V + 2) * cw] = f2u(n_view.z);
+                    r[(WK_ATT + 0) * cw] = f2u(n_att.x);
+                    r[(WK_ATT + 1) * cw] = f2u(n_att.y);
+                    r[(WK_ATT + 2) * cw] = f2u(n_att.z);
+                    r[(WK_ATT + 3) * cw] = f2u(n_att.w);
+                    r[WK_GEOM * cw] = n_geom;
+                    r[(WK_RNG + 0) * cw] = rng.v0;
+                    r[(WK_RNG + 1) * cw] = rng.v1;
+                    r[(WK_RNG + 2) * cw] = rng.v2;
+                    r[(WK_RNG + 3) * cw] = rng.v3;
+                    r[(WK_RNG + 4) * cw] = rng.v4;
+                    r[(WK_RNG + 5) * cw] = rng.d;
+                    r[WK_SLOT * cw] = (uint32_t)((size_t)slot_k * n_lp + lp);
+                } else {
+                    w.ctrs[WF_CTR_ERROR] = 1u;
+                }
+                // the light samples of this hit (drawn by the filter kernel from the recorded state)
+                for (uint32_t k = 0; k < skip_draws; ++k) rng_step(rng);
+                if (n_depth > 0u) {
+                    ++cnt_expand;
+                    // The reference draws (r1,r2) for every child and pushes while its stack has room (main.cu:176-191).
+                    uint32_t room = on_stack < CRT_RAY_STACK ? CRT_RAY_STACK - on_stack : 0u;
+                    uint32_t accepted = a.ind_rays < room ? a.ind_rays : room;
+                    for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
+                    if (accepted > 0u) {
+                        uint32_t* f = w.frames + ((size_t)nframes * WF_FRAME_PLANES) * n_lp + lp;
+                        ++nframes;
+                        f[(FR_P + 0) * n_lp] = f2u(n_P.x);
+                        f[(FR_P + 1) * n_lp] = f2u(n_P.y);
+                        f[(FR_P + 2) * n_lp] = f2u(n_P.z);
+                        f[(FR_N + 0) * n_lp] = f2u(n_N.x);
+                        f[(FR_N + 1) * n_lp] = f2u(n_N.y);
+                        f[(FR_N + 2) * n_lp] = f2u(n_N.z);
+                        f[(FR_ATT + 0) * n_lp] = f2u(n_att.x);
+                        f[(FR_ATT + 1) * n_lp] = f2u(n_att.y);
+                        f[(FR_ATT + 2) * n_lp] = f2u(n_att.z);
+                        f[(FR_ATT + 3) * n_lp] = f2u(n_att.w);
+                        f[(FR_RNG + 0) * n_lp] = rng.v0;
+                        f[(FR_RNG + 1) * n_lp] = rng.v1;
+                        f[(FR_RNG + 2) * n_lp] = rng.v2;
+                        f[(FR_RNG + 3) * n_lp] = rng.v3;
+                        f[(FR_RNG + 4) * n_lp] = rng.v4;
+                        f[(FR_RNG + 5) * n_lp] = rng.d;
+                        f[FR_GEOM * n_lp] = n_geom;
+                        f[FR_REMAINING * n_lp] = accepted;
+                        f[FR_CHILD_DEPTH * n_lp] = n_depth - 1u;
+                        on_stack += accepted;
+                    }
+                    for (uint32_t k = 2u * accepted; k < 2u * a.ind_rays; ++k) rng_step(rng);
+                }
+            }
+        }
+    }
+
+    // ---- the unused tail of the last chunk holds no record
+    if (have_chunk)
+        for (uint32_t k = chunk_used + lane; k < kWorkChunk; k += 64u)
+            if (chunk_base + k < w.cap_work) w.work[(size_t)WK_GEOM * w.cap_work + chunk_base + k] = kNoRecord;
+
+    // ---- park the traversal
+    w.slot_count[lp] = cnt;
+    if (live_at_entry) {
+        a.rng[0 * (size_t)npix + pix] = rng.v0;
+        a.rng[1 * (size_t)npix + pix] = rng.v1;
+        a.rng[2 * (size_t)npix + pix] = rng.v2;
+        a.rng[3 * (size_t)npix + pix] = rng.v3;
+        a.rng[4 * (size_t)npix + pix] = rng.v4;
+        a.rng[5 * (size_t)npix + pix] = rng.d;
+        a.counters[pix] += cnt_shade;
+        a.counters[npix + pix] += cnt_expand;
+        uint32_t* s = w.state + lp;
+        s[ST_CTL * n_lp] = (done ? 1u : 0u) | (color_active ? 2u : 0u) | (cur_valid ? 4u : 0u) | (call << 4) | (nframes << 8);
+        if (!done) {
+            s[(ST_CUR_O + 0) * n_lp] = f2u(cur_o.x);
+            s[(ST_CUR_O + 1) * n_lp] = f2u(cur_o.y);
+            s[(ST_CUR_O + 2) * n_lp] = f2u(cur_o.z);
+            s[(ST_CUR_D + 0) * n_lp] = f2u(cur_d.x);
+            s[(ST_CUR_D + 1) * n_lp] = f2u(cur_d.y);
+            s[(ST_CUR_D + 2) * n_lp] = f2u(cur_d.z);
+            s[(ST_CUR_ATT + 0) * n_lp] = f2u(cur_att.x);
+            s[(ST_CUR_ATT + 1) * n_lp] = f2u(cur_att.y);
+            s[(ST_CUR_ATT + 2) * n_lp] = f2u(cur_att.z);
+            s[(ST_CUR_ATT + 3) * n_lp] = f2u(cur_att.w);
+            s[ST_CUR_REF * n_lp] = cur_ref;
+            s[ST_CUR_DEPTH * n_lp] = cur_depth;
+            s[(ST_RAY_D + 0) * n_lp] = f2u(ray_d.x);
+            s[(ST_RAY_D + 1) * n_lp] = f2u(ray_d.y);
+            s[(ST_RAY_D + 2) * n_lp] = f2u(ray_d.z);
+            s[ST_ON_STACK * n_lp] = on_stack;
+        }
+    } else if (first) {
+        w.state[ST_CTL * n_lp + lp] = 1u; // pixel slots outside the image never run
+    }
+    const uint64_t alive = __ballot(!done);
+    if (lane == 0 && alive != 0) atomicAdd(&w.ctrs[WF_CTR_ACTIVE], (uint32_t)__popcll(alive));
+}
+
+// --------------------------------------------------------------------------------------- filter
+// Constants of AreaLight::_randomPoint (AreaLight.hpp:340-375) in scalar registers.
+struct LightC {
+    V3 pos, p0, p2, e01, e03, e23, e21;
+};
+DI LightC load_lightc(const DevLight CRT_CONST* L) {
+    LightC c;
+    c.pos = ld3c(L->pos);
+    c.p0 = ld3c(L->p0);
+    c.p2 = ld3c(L->p2);
+    c.e01 = ld3c(L->e01);
+    c.e03 = ld3c(L->e03);
+    c.e23 = ld3c(L->e23);
+    c.e21 = ld3c(L->e21);
+    return c;
+}
+// Shadow ray of one light sample (AreaLight.hpp:340-375,495-510; Ray.hpp:45-52).
+DI void shadow_ray(const LightC& lc, V3 P, float u, float v, V3& o, V3& d, float& x) {
+    V3 sample;
+    if (u + v < 1.0f) {
+        sample = ((lc.p0 + lc.e01 * u) + lc.e03 * v) + lc.pos;
+    } else {
+        u = 1.0f - u;
+        v = 1.0f - v;
+        sample = ((lc.p2 + lc.e23 * u) + lc.e21 * v) + lc.pos;
+    }
+    V3 dir = sample - P;
+    float dist;
+    V3 ndir = normalize3_len(dir, dist);
+    if (!eps_equal(dist, 0.0f, kEps)) dir = ndir;
+    o = P + dir * 0.01f;
+    d = ray_dir(dir);         // the Ray ctor normalises once more
+    x = max_std(0.0f, dist);  // Ray::setDistance
+}
+
+constexpr uint32_t kStageCap = 128; // < 64 left over + 64 new entries per append
+
+struct Stage {
+    uint32_t head, fill; // wave-uniform ring cursor
+    uint32_t written;    // entries already moved to the queue
+};
+
+// Moves `n` staged entries (n <= 64) to this wave's region of the queue.
+DI void stage_flush(const WfArgs& w, uint32_t (*stg)[kStageCap], Stage& st, uint32_t n, uint32_t lane) {
+    __syncthreads();
+    if (lane < n) {
+        const uint32_t pos = (st.head + lane) & (kStageCap - 1u);
+        const uint32_t k = st.written + lane;
+        if (k < w.region_cap) {
+            const size_t idx = (size_t)blockIdx.x * w.region_cap + k;
+            w.queue[idx] = stg[0][pos];
+            w.queue[(size_t)w.qcap + idx] = stg[1][pos];
+            w.queue[2 * (size_t)w.qcap + idx] = stg[2][pos];
+        } else {
+            w.ctrs[WF_CTR_ERROR] = 2u;
+        }
+    }
+    st.head = (st.head + n) & (kStageCap - 1u);
+    st.fill -= n;
+    st.written += n;
+    __syncthreads();
+}
+
+template <int NB>
+DI void filter_block(const WfArgs& w, ScenePtr sc, const LightC& lc, uint64_t prim_mask, bool act, V3 P, Rng& rng,
+                     uint32_t key, uint32_t& shadowed, uint32_t (*stg)[kStageCap], Stage& st, uint32_t lane,
+                     uint32_t& tally) {
+    V3 o[NB], d[NB];
+    float x[NB], us[NB], vs[NB], dd4[NB];
+    bool ddok[NB], xok[NB];
+    uint32_t sure_opaque = 0, maybe_any = 0, maybe_glass = 0; // bit j = sample j of the block
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        us[j] = rng_uniform(rng);
+        vs[j] = rng_uniform(rng);
+        shadow_ray(lc, P, us[j], vs[j], o[j], d[j], x[j]);
+        const float dd = dot3(d[j], d[j]);
+        dd4[j] = 4.0f * dd; // 4.f * a (Sphere.hpp:61)
+        ddok[j] = dd > 1e-6f && dd < 1e6f;
+        xok[j] = x[j] > 1e-30f && x[j] < 1e30f;
+    }
+    uint64_t m = prim_mask;
+    while (m != 0) {
+        const uint32_t i = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1u;
+        const DevGeomHot CRT_CONST* g = &sc->hot[i];
+        const uint32_t kind = g->kind;
+        const bool glass = g->mat_type == CRT_MAT_REFRACTIVE;
+        const V3 go = ld3c(g->o), gn = ld3c(g->n);
+        if (kind == CRT_GEOM_SPHERE) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const uint32_t c = sphere_class(go, gn.x, o[j], d[j], dd4[j], ddok[j], x[j]);
+                if (glass) {
+                    if (c != 0u) {
+                        maybe_any |= 1u << j;
+                        maybe_glass |= 1u << j;
+                    }
+                } else {
+                    if (c == 1u) maybe_any |= 1u << j;
+                    if (c == 2u) sure_opaque |= 1u << j;
+                }
+            }
+        } else {
+            const DevGeomBox CRT_CONST* bx = &sc->box[i];
+            const V3 blo = ld3c(bx->lo), bhi = ld3c(bx->hi);
+            const float min_adn = bx->min_adn;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                float pn, dn;
+                if (kind == CRT_HOT_QUAD_X) {
+                    pn = (o[j].x - go.x) * gn.x;
+                    dn = d[j].x * gn.x;
+                } else if (kind == CRT_HOT_QUAD_Y) {
+                    pn = (o[j].y - go.y) * gn.y;
+                    dn = d[j].y * gn.y;
+                } else if (kind == CRT_HOT_QUAD_Z) {
+                    pn = (o[j].z - go.z) * gn.z;
+                    dn = d[j].z * gn.z;
+                } else {
+                    const V3 p = o[j] - go;
+                    pn = p.x * gn.x + p.y * gn.y + p.z * gn.z;
+                    dn = d[j].x * gn.x + d[j].y * gn.y + d[j].z * gn.z;
+                }
+                const bool h = plane_may_hit(pn, dn, x[j], xok[j]) && box_may_hit(blo, bhi, min_adn, o[j], d[j], pn, dn);
+                if (h) {
+                    maybe_any |= 1u << j;
+                    if (glass) maybe_glass |= 1u << j;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const bool so = (sure_opaque >> j) & 1u, ma = (maybe_any >> j) & 1u, mg = (maybe_glass >> j) & 1u;
+        const bool covered = act && so && !mg; // the closest hit is opaque whichever primitive it is
+        const bool unresolved = act && !covered && (ma || so);
+        if (covered) ++shadowed;
+        const uint64_t bm = __ballot(unresolved);
+        if (bm != 0) {
+            if (unresolved) {
+                const uint32_t pos = (st.head + st.fill + lane_rank(bm)) & (kStageCap - 1u);
+                stg[0][pos] = key;
+                stg[1][pos] = f2u(us[j]);
+                stg[2][pos] = f2u(vs[j]);
+            }
+            st.fill += (uint32_t)__popcll(bm);
+            tally += (uint32_t)__popcll(bm);
+            if (st.fill >= 64u) stage_flush(w, stg, st, 64u, lane);
+        }
+    }
+}
+
+#ifndef CRT_WF_FILTER_WAVES
+#define CRT_WF_FILTER_WAVES 6
+#endif
+__global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end) {
+    ScenePtr sc = (ScenePtr)w.r.scene;
+    const uint32_t lane = threadIdx.x;
+    __shared__ uint32_t stg[3][kStageCap];
+    Stage st = {0u, 0u, 0u};
+    uint32_t tally = 0;
+    const size_t cw = w.cap_work;
+    const uint32_t n_geom = sc->n_geom, n_lights = sc->n_lights;
+    for (uint32_t base = blockIdx.x * 64u; base < w_end - w_begin; base += gridDim.x * 64u) {
+        const uint32_t wi = w_begin + base + lane;
+        const uint32_t wr = wi < w_end ? wi : w_begin; // tail lanes shadow a valid index and discard the result
+        const bool act = wi < w_end && w.work[(size_t)WK_GEOM * cw + wr] != kNoRecord;
+        const uint32_t* r = w.work + wr;
+        const V3 P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
+        Rng rng;
+        rng.v0 = r[(WK_RNG + 0) * cw];
+        rng.v1 = r[(WK_RNG + 1) * cw];
+        rng.v2 = r[(WK_RNG + 2) * cw];
+        rng.v3 = r[(WK_RNG + 3) * cw];
+        rng.v4 = r[(WK_RNG + 4) * cw];
+        rng.d = r[(WK_RNG + 5) * cw];
+        for (uint32_t li = 0; li < n_lights; ++li) {
+            const DevLight CRT_CONST* L = &sc->lights[li];
+            if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue; // no draws (Light.hpp:92-111, AreaLight.hpp:586)
+            const uint32_t S = L->shadow_samples;
+            const LightC lc = load_lightc(L);
+            // primitives that may stop a shadow ray of some record of this wave
+            uint64_t prim_mask = 0;
+            for (uint32_t i = 0; i < n_geom; ++i) {
+                const DevGeomHot CRT_CONST* g = &sc->hot[i];
+                bool keep = true;
+                if (g->kind != CRT_GEOM_SPHERE) {
+                    const V3 q = P - ld3c(g->o);
+                    const float s = (q.x * g->n[0] + q.y * g->n[1]) + q.z * g->n[2];
+                    keep = !(s * sc->cull_side[li][i] > sc->cull_thr[li][i]);
+                }
+                if (__any(keep)) prim_mask |= 1ull << i;
+            }
+            uint32_t shadowed = 0;
+            const uint32_t key = wi | (li << 28);
+            uint32_t s = 0;
+            for (; s + 5u <= S; s += 5u)
+                filter_block<5>(w, sc, lc, prim_mask, act, P, rng, key, shadowed, stg, st, lane, tally);
+            for (; s < S; ++s) filter_block<1>(w, sc, lc, prim_mask, act, P, rng, key, shadowed, stg, st, lane, tally);
+            if (act) w.shadow_cnt[(size_t)li * cw + wi] = shadowed;
+        }
+    }
+    if (st.fill != 0u) stage_flush(w, stg, st, st.fill, lane);
+    if (lane == 0) w.qcounts[blockIdx.x] = st.written;
+    if (lane == 0 && tally != 0u) atomicAdd(&w.r.wave_tallies[0], (unsigned long long)tally);
+}
+
+// -------------------------------------------------------------------------------------- resolve
+__global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
+    ScenePtr sc = (ScenePtr)w.r.scene;
+    const uint32_t lane = threadIdx.x;
+    const size_t cw = w.cap_work;
+    const uint32_t n_lights = sc->n_lights;
+    const uint32_t qcount = min(w.qcounts[blockIdx.x], w.region_cap);
+    const size_t region = (size_t)blockIdx.x * w.region_cap;
+    uint32_t glass_tally = 0;
+    for (uint32_t base = 0; base < qcount; base += 64u) {
+        const bool act = base + lane < qcount;
+        const size_t idx = region + base + lane;
+        uint32_t key = 0;
+        float u = 0.0f, v = 0.0f;
+        V3 P = mk3(0, 0, 0);
+        if (act) {
+            key = w.queue[idx];
+            u = u2f(w.queue[(size_t)w.qcap + idx]);
+            v = u2f(w.queue[2 * (size_t)w.qcap + idx]);
+            const uint32_t* r = w.work + (key & 0x0fffffffu);
+            P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
+        }
+        const uint32_t my_light = key >> 28;
+        for (uint32_t li = 0; li < n_lights; ++li) {
+            const bool mine = act && my_light == li;
+            if (!__any(mine)) continue;
+            const DevLight CRT_CONST* L = &sc->lights[li];
+            const LightC lc = load_lightc(L);
+            if (mine) {
+                V3 o, d;
+                float x;
+                shadow_ray(lc, P, u, v, o, d, x);
+                // Light::_isCovered (Light.hpp:35-86)
+                Hit h = closest_hit(sc, o, d, x);
+                bool covered = false;
+                if (h.idx >= 0) {
+                    if (h.mat_type != CRT_MAT_REFRACTIVE) {
+                        covered = true;
+                    } else {
+                        ++glass_tally;
+                        covered = covered_through_glass(sc, L, o, d, h);
+                    }
+                }
+                if (covered) atomicAdd(&w.shadow_cnt[(size_t)li * cw + (key & 0x0fffffffu)], 1u);
+            }
+        }
+    }
+    // wave sum of the glass tally
+    for (int off = 32; off > 0; off >>= 1) glass_tally += __shfl_down(glass_tally, off, 64);
+    if (lane == 0 && glass_tally != 0u) atomicAdd(&w.r.wave_tallies[1], (unsigned long long)glass_tally);
+}
+
+// ---------------------------------------------------------------------------------------- shade
+__global__ void __launch_bounds__(64, 4) wf_shade_kernel(WfArgs w, uint32_t n_work) {
+    ScenePtr sc = (ScenePtr)w.r.scene;
+    const uint32_t wi = blockIdx.x * 64u + threadIdx.x;
+    if (wi >= n_work) return;
+    const size_t cw = w.cap_work;
+    const uint32_t* r = w.work + wi;
+    const V3 P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
+    const V3 N = mk3(u2f(r[(WK_N + 0) * cw]), u2f(r[(WK_N + 1) * cw]), u2f(r[(WK_N + 2) * cw]));
+    const V3 view = mk3(u2f(r[(WK_V + 0) * cw]), u2f(r[(WK_V + 1) * cw]), u2f(r[(WK_V + 2) * cw]));
+    const V4 att = V4{u2f(r[(WK_ATT + 0) * cw]), u2f(r[(WK_ATT + 1) * cw]), u2f(r[(WK_ATT + 2) * cw]),
+                      u2f(r[(WK_ATT + 3) * cw])};
+    const uint32_t geom = r[WK_GEOM * cw];
+    if (geom == kNoRecord) return;
+    const uint32_t slot = r[WK_SLOT * cw];
+    const DevGeomShade CRT_CONST* gs = &sc->shade[geom];
+    V4 direct = V4{0, 0, 0, 0}; // LightList::calculateColor (LightList.hpp:23-36)
+    const uint32_t n_lights = sc->n_lights;
+    for (uint32_t li = 0; li < n_lights; ++li) {
+        const DevLight CRT_CONST* L = &sc->lights[li];
+        if (L->kind != CRT_LIGHT_AREA) {
+            direct = direct + point_light_color(sc, L, gs, P, N, view);
+        } else if (!L->initialized) { // AreaLight.hpp:586
+            V3 amb = mk3(gs->ambient[0], gs->ambient[1], gs->ambient[2]) * ld3c(L->color);
+            direct = direct + V4{amb.x, amb.y, amb.z, 1.0f};
+        } else {
+            const uint32_t S = L->shadow_samples;
+            const uint32_t shadowed = w.shadow_cnt[(size_t)li * cw + wi];
+            float visibility = 1.0f - ((float)shadowed / (float)S); // AreaLight.hpp:527
+            direct = direct + area_light_shade(w.r.ltc, L, gs, P, N, view, visibility);
+        }
+    }
+    const V4 c = att * direct; // final_color += attenuation * light (main.cu:195)
+    w.contrib[slot] = make_float4(c.x, c.y, c.z, c.w);
+}
+
+// ------------------------------------------------------------------------------------------ sum
+__global__ void __launch_bounds__(64) wf_sum_kernel(WfArgs w, uint32_t first) {
+    const RenderArgs& a = w.r;
+    const uint32_t lane = threadIdx.x, unit = blockIdx.x;
+    const size_t n_lp = w.n_lp;
+    const size_t lp = (size_t)unit * 64u + lane;
+    const uint32_t cnt = w.slot_count[lp];
+    if (cnt == 0u && !first) return;
+    V4 final_c = V4{0, 0, 0, 0}, acc = V4{0, 0, 0, 0};
+    if (!first) {
+        const float4 f = w.px_acc[lp], g = w.px_acc[n_lp + lp];
+        final_c = V4{f.x, f.y, f.z, f.w};
+        acc = V4{g.x, g.y, g.z, g.w};
+    }
+    // weights of aa_color for a level-0 / level-1 task (main.cu:254-268)
+    const float mult = 1.0f / (float)(1u << 0);
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t tag = w.tags[(size_t)k * n_lp + lp];
+        if (tag == TAG_ADD) {
+            const float4 c = w.contrib[(size_t)k * n_lp + lp];
+            final_c = final_c + V4{c.x, c.y, c.z, c.w};
+        } else if (tag == TAG_END_CALL) {
+            if (a.aa_iter == 0u) acc = acc + final_c * mult;
+            else acc = acc + (final_c * mult) * 0.25f;
+            final_c = V4{0, 0, 0, 0};
+        } else {
+            // render() epilogue (main.cu:339-346)
+            const PixelMap pm = map_pixel(a, unit, lane);
+            reinterpret_cast<float4*>(a.out)[pm.out_index] =
+                make_float4(saturate_c(acc.x), saturate_c(acc.y), saturate_c(acc.z), saturate_c(acc.w));
+        }
+    }
+    w.px_acc[lp] = make_float4(final_c.x, final_c.y, final_c.z, final_c.w);
+    w.px_acc[n_lp + lp] = make_float4(acc.x, acc.y, acc.z, acc.w);
+}
+
+int g_resident_cus[64] = {0};
+
+} // namespace
+
+bool wavefront_supports(const RenderArgs& args) { return args.aa_iter <= 1u; }
+
+void wavefront_release(WfWorkspace& ws) {
+    (void)hipFree(ws.ctrs);
+    (void)hipHostFree(ws.ctrs_host);
+    (void)hipFree(ws.state);
+    (void)hipFree(ws.frames);
+    (void)hipFree(ws.tags);
+    (void)hipFree(ws.contrib);
+    (void)hipFree(ws.slot_count);
+    (void)hipFree(ws.px_acc);
+    (void)hipFree(ws.work);
+    (void)hipFree(ws.shadow_cnt);
+    (void)hipFree(ws.queue);
+    (void)hipFree(ws.qcounts);
+    ws = WfWorkspace();
+}
+
+hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n_lights, size_t budget_bytes) {
+    const uint32_t n_lp = args.n_units * 64u;
+    if (n_lp == 0) return hipSuccess;
+    // Slots one pixel can fill in total: per color() call one per popped ray that can end in a hit or a
+    // miss (1 + ind + ind^2 + ...), one end-of-call marker; one end-of-pixel marker.
+    const uint64_t calls = args.aa_iter == 0u ? 1u : 4u;
+    uint64_t rays = 1, level = 1;
+    for (uint32_t g = 0; g < args.gl_iter && rays < (1ull << 32); ++g) {
+        level *= args.ind_rays;
+        rays += level;
+    }
+    uint64_t want = calls * (rays + 1u) + 1u;
+    const uint32_t lights = n_lights ? n_lights : 1u;
+    // bytes per pixel slot and quota unit: tag 1 + contribution 16 + shade record planes + shadow counts
+    const uint64_t per_slot = 1u + 16u + 4u * WF_WORK_PLANES + 4u * lights;
+    uint64_t quota_max = budget_bytes / (per_slot * n_lp);
+    if (quota_max < 16u) quota_max = 16u;
+    if (want > quota_max) want = quota_max;
+    if ((want + kWorkChunk / 64u) * n_lp >= (1ull << 28)) { // record index and light share one word
+        want = ((1ull << 28) - 1u) / n_lp - kWorkChunk / 64u;
+        if (want < 8u) return hipErrorOutOfMemory; // more than 2^25 pixel slots in one launch
+    }
+    const uint32_t quota = (uint32_t)want;
+    const uint32_t levels = args.gl_iter ? args.gl_iter : 1u;
+    if (ws.n_lp == n_lp && ws.quota >= quota && ws.gl_levels >= levels && ws.n_lights >= lights) return hipSuccess;
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    wavefront_release(ws);
+    const uint32_t cap_work = quota * n_lp + args.n_units * kWorkChunk; // + every trace wave's partly used chunk
+    // every filter wave owns a region of the queue that holds all shadow rays of its records; 2^28 rays (3.2 GB)
+    const uint32_t qcap = 1u << 28;
+    size_t total = 0;
+    auto grab = [&](void** p, size_t bytes) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(p, bytes);
+        total += bytes;
+    };
+    grab((void**)&ws.ctrs, WF_CTR_COUNT * 16u * sizeof(uint32_t));
+    grab((void**)&ws.state, (size_t)WF_STATE_PLANES * n_lp * 4u);
+    grab((void**)&ws.frames, (size_t)levels * WF_FRAME_PLANES * n_lp * 4u);
+    grab((void**)&ws.tags, (size_t)quota * n_lp);
+    grab((void**)&ws.contrib, (size_t)quota * n_lp * 16u);
+    grab((void**)&ws.slot_count, (size_t)n_lp * 4u);
+    grab((void**)&ws.px_acc, (size_t)2u * n_lp * 16u);
+    grab((void**)&ws.work, (size_t)WF_WORK_PLANES * cap_work * 4u);
+    grab((void**)&ws.shadow_cnt, (size_t)lights * cap_work * 4u);
+    grab((void**)&ws.queue, (size_t)3u * qcap * 4u);
+    grab((void**)&ws.qcounts, (size_t)kMaxFilterWaves * 4u);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ws.ctrs_host, WF_CTR_COUNT * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        wavefront_release(ws);
+        return e;
+    }
+    ws.n_lp = n_lp;
+    ws.quota = quota;
+    ws.gl_levels = levels;
+    ws.cap_work = cap_work;
+    ws.n_lights = lights;
+    ws.qcap = qcap;
+    ws.bytes = total;
+    return hipSuccess;
+}
+
+hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow) {
+    *overflow = false;
+    if (args.n_units == 0) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (g_resident_cus[dev] == 0) {
+        int cus = 0;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        g_resident_cus[dev] = cus > 0 ? cus : 1;
+    }
+    const uint32_t cus = (uint32_t)g_resident_cus[dev];
+
+    WfArgs w;
+    w.r = args;
+    w.n_lp = ws.n_lp;
+    w.quota = ws.quota;
+    w.cap_work = ws.cap_work;
+    w.qcap = ws.qcap;
+    w.ctrs = ws.ctrs;
+    w.state = ws.state;
+    w.frames = ws.frames;
+    w.tags = ws.tags;
+    w.contrib = reinterpret_cast<float4*>(ws.contrib);
+    w.slot_count = ws.slot_count;
+    w.px_acc = reinterpret_cast<float4*>(ws.px_acc);
+    w.work = ws.work;
+    w.shadow_cnt = ws.shadow_cnt;
+    w.queue = ws.queue;
+    w.qcounts = ws.qcounts;
+    w.region_cap = 0;
+
+    // shadow rays per shade record, for sizing the filter batches
+    // Filter launches: G persistent waves, each takes every G-th group of 64 records and owns a queue
+    // region large enough for all shadow rays of its groups.
+    const uint64_t rays_per_group = 64ull * (args.max_shadow_rays ? args.max_shadow_rays : 1u);
+    uint32_t fwaves = cus * 4u * CRT_WF_FILTER_WAVES;
+    if (fwaves > kMaxFilterWaves) fwaves = kMaxFilterWaves;
+    if ((uint64_t)fwaves * rays_per_group > ws.qcap) fwaves = (uint32_t)(ws.qcap / rays_per_group);
+    if (fwaves == 0) return hipErrorInvalidValue; // a single group's shadow rays exceed the queue
+    const uint32_t groups_per_wave = (uint32_t)(ws.qcap / ((uint64_t)fwaves * rays_per_group));
+    const uint64_t batch64 = (uint64_t)groups_per_wave * fwaves * 64u;
+    const uint32_t batch = batch64 > 0x40000000ull ? 0x40000000u : (uint32_t)batch64;
+    w.region_cap = (uint32_t)(groups_per_wave * rays_per_group);
+
+    uint32_t first = 1u;
+    e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_COUNT * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    for (;;) {
+        e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_ERROR * sizeof(uint32_t), stream); // the error word is sticky
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(wf_trace_kernel, dim3(args.n_units), dim3(64), 0, stream, w, first);
+        e = hipMemcpyAsync(ws.ctrs_host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        const uint32_t n_work = ws.ctrs_host[WF_CTR_WORK];
+        const uint32_t n_active = ws.ctrs_host[WF_CTR_ACTIVE];
+        if (ws.ctrs_host[WF_CTR_ERROR] != 0u || n_work > ws.cap_work) {
+            *overflow = true;
+            return hipSuccess;
+        }
+        for (uint32_t b0 = 0; b0 < n_work; b0 += batch) {
+            const uint32_t b1 = n_work - b0 > batch ? b0 + batch : n_work;
+            const uint32_t groups = (b1 - b0 + 63u) / 64u;
+            const uint32_t fgrid = groups < fwaves ? groups : fwaves;
+            hipLaunchKernelGGL(wf_filter_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
+            hipLaunchKernelGGL(wf_resolve_kernel, dim3(fgrid), dim3(64), 0, stream, w);
+        }
+        if (n_work != 0u)
+            hipLaunchKernelGGL(wf_shade_kernel, dim3((n_work + 63u) / 64u), dim3(64), 0, stream, w, n_work);
+        hipLaunchKernelGGL(wf_sum_kernel, dim3(args.n_units), dim3(64), 0, stream, w, first);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        first = 0u;
+        if (n_active == 0u) break;
+    }
+    // the error word of the last filter batches
+    e = hipMemcpyAsync(ws.ctrs_host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    if (ws.ctrs_host[WF_CTR_ERROR] != 0u) *overflow = true;
+    return hipSuccess;
+}
+
+} // namespace crt

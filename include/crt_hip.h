@@ -210,6 +210,21 @@ int crt_scatter_shards(crt_ctx* ctx, uint32_t nx, uint32_t ny, uint32_t world,
  * (computed from the RNG draw counters and the settings).  Synchronous. */
 int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out);
 
+/* Which kernels crt_render / crt_render_partial / crt_render_shard run.  Both give the same bits.
+ *   CRT_PIPELINE_AUTO        wavefront where it applies (aa_iter <= 1), else persistent (default)
+ *   CRT_PIPELINE_PERSISTENT  one persistent kernel per launch, asynchronous on `stream`
+ *   CRT_PIPELINE_WAVEFRONT   trace / filter / resolve / shade / sum kernels with records in device
+ *                            memory; the call returns after the image is complete (it synchronises
+ *                            `stream` once per round); CRT_ERR_UNSUPPORTED at render time if aa_iter > 1
+ * The reference has one kernel and no such switch (main.cu:328-347). */
+#define CRT_PIPELINE_AUTO 0
+#define CRT_PIPELINE_PERSISTENT 1
+#define CRT_PIPELINE_WAVEFRONT 2
+int crt_set_pipeline(crt_ctx* ctx, int pipeline);
+/* Upper bound in bytes of the wavefront pipeline's device workspace (default 32 GiB); a smaller
+ * bound means more rounds per image, never a different image.  No counterpart in the reference. */
+int crt_set_workspace_limit(crt_ctx* ctx, size_t bytes);
+
 /* Device self-test: compares the kernels' fast correctly-rounded reciprocal with
  * the IEEE quotient 1.0f/x for all 2^32 float bit patterns.  Returns the number
  * of mismatches (expected 0) and the smallest mismatching bit pattern

@@ -20,10 +20,14 @@ def oracle():
     return oracle_lib
 
 
-@pytest.fixture(scope="session")
-def gpu_ctx():
-    """One context on cuda:0 shared by the GPU tests (fails loudly without the HIP library or a GPU)."""
+@pytest.fixture(scope="session", params=["auto", "persistent"])
+def gpu_ctx(request):
+    """One context per pipeline on cuda:0 shared by the GPU tests (fails loudly without the HIP library
+    or a GPU).  "auto" runs the wavefront kernels wherever they apply (aa_iter <= 1)."""
     import cudaraytracer_amd as crt
+    from cudaraytracer_amd import abi
     ctx = crt.Context(0)
+    ctx.set_pipeline(abi.CRT_PIPELINE_AUTO if request.param == "auto" else abi.CRT_PIPELINE_PERSISTENT)
+    ctx.pipeline_name = request.param
     yield ctx
     ctx.close()
