@@ -58,6 +58,8 @@ def lib():
             "crt_selftest_rcp": (C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint32)]),
             "crt_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
             "crt_set_workspace_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
+            "crt_set_audit": (C.c_int, [C.c_void_p, C.c_int]),
+            "crt_audit_result": (C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint64)]),
             "crt_fb_alloc": (C.c_int, [C.c_void_p, C.c_size_t, P(C.c_void_p)]),
             "crt_fb_free": (C.c_int, [C.c_void_p, C.c_void_p]),
             "crt_fb_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -76,7 +78,7 @@ ABI_SYMBOLS = (
     "crt_create", "crt_destroy", "crt_last_error", "crt_cornell_scene", "crt_scene_upload", "crt_rng_init",
     "crt_rng_export", "crt_render", "crt_render_partial", "crt_render_shard", "crt_shard_tiles",
     "crt_shard_tiles_max", "crt_scatter_shards", "crt_stats_since_init", "crt_selftest_rcp", "crt_set_pipeline",
-    "crt_set_workspace_limit", "crt_fb_alloc", "crt_fb_free",
+    "crt_set_workspace_limit", "crt_set_audit", "crt_audit_result", "crt_fb_alloc", "crt_fb_free",
     "crt_fb_download", "crt_write_hdr", "crt_encode_hdr")
 
 
@@ -171,6 +173,15 @@ class Context:
 
     def set_workspace_limit(self, nbytes):
         self._check(lib().crt_set_workspace_limit(self._h, nbytes), "crt_set_workspace_limit")
+
+    def set_audit(self, enabled):
+        self._check(lib().crt_set_audit(self._h, int(bool(enabled))), "crt_set_audit")
+
+    def audit_result(self):
+        """(rays decided by the conservative filter and re-checked exactly, contradictions)."""
+        n, bad = C.c_uint64(), C.c_uint64()
+        self._check(lib().crt_audit_result(self._h, C.byref(n), C.byref(bad)), "crt_audit_result")
+        return n.value, bad.value
 
     def selftest_rcp(self):
         """(mismatches, first mismatching bit pattern) of the fast reciprocal vs 1.0f/x over all floats."""

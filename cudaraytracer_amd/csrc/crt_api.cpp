@@ -28,6 +28,7 @@ struct crt_ctx {
     uint32_t* unit_counter = nullptr; // work-unit cursor of the persistent render grid
     uint32_t rng_nx = 0, rng_ny = 0;
     int pipeline = CRT_PIPELINE_AUTO;
+    int audit = 0;
     size_t workspace_limit = (size_t)32 << 30;
     crt::WfWorkspace wf;
 };
@@ -89,6 +90,7 @@ crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
     a.tiles_x = (st->nx + 7u) / 8u;
     a.tiles_y = (st->ny + 7u) / 8u;
     a.world = 1;
+    a.audit = ctx->audit ? 1u : 0u;
     for (uint32_t l = 0; l < ctx->scene_host.n_lights; ++l) {
         const crt::DevLight& L = ctx->scene_host.lights[l];
         if (L.kind == CRT_LIGHT_AREA && L.initialized) a.max_shadow_rays += L.shadow_samples;
@@ -191,7 +193,7 @@ int crt_rng_init(crt_ctx* ctx, uint32_t nx, uint32_t ny, uint64_t seed, void* st
     HIP_TRY(ctx, hipMemcpyAsync(ctx->rng_init_d, ctx->rng_dev + 5 * npix, npix * sizeof(uint32_t),
                                 hipMemcpyDeviceToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->counters_dev, 0, npix * 2 * sizeof(uint32_t), s));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->unit_counter + 16, 0, 16, s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->unit_counter + 16, 0, 32, s));
     return CRT_OK;
 }
 
@@ -330,6 +332,25 @@ int crt_set_pipeline(crt_ctx* ctx, int pipeline) {
     if (pipeline != CRT_PIPELINE_AUTO && pipeline != CRT_PIPELINE_PERSISTENT && pipeline != CRT_PIPELINE_WAVEFRONT)
         return fail(ctx, CRT_ERR_INVALID, "unknown pipeline %d", pipeline);
     ctx->pipeline = pipeline;
+    return CRT_OK;
+}
+
+int crt_set_audit(crt_ctx* ctx, int enabled) {
+    if (!ctx) return CRT_ERR_INVALID;
+    ctx->audit = enabled ? 1 : 0;
+    return CRT_OK;
+}
+
+int crt_audit_result(crt_ctx* ctx, uint64_t* checked, uint64_t* contradictions) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!checked || !contradictions) return fail(ctx, CRT_ERR_INVALID, "NULL argument");
+    int rc = bind(ctx);
+    if (rc != CRT_OK) return rc;
+    unsigned long long t[2] = {0, 0};
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(t, ctx->unit_counter + 20, 16, hipMemcpyDeviceToHost));
+    *checked = t[0];
+    *contradictions = t[1];
     return CRT_OK;
 }
 

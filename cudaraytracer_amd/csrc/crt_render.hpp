@@ -19,7 +19,7 @@ struct RenderArgs {
     uint32_t* rng;    // 6 planes of nx*ny words: v0..v4, d
     uint32_t* counters; // 2 planes of nx*ny words: shaded diffuse hits, expanding hits (accumulated)
     float* out;
-    unsigned long long* wave_tallies; // [0] rays sent to stage 2, [1] rays sent to the glass walk (accumulated)
+    unsigned long long* wave_tallies; // [0] rays sent to the exact test, [1] rays sent to the glass walk, [2] rays the filter audit checked, [3] audit contradictions (accumulated)
     uint32_t* unit_counter; // global work-unit cursor (zeroed by launch_render)
     uint32_t n_units;       // 64-pixel work units in this launch
     uint32_t nx, ny;
@@ -28,6 +28,7 @@ struct RenderArgs {
     uint32_t tiles_x, tiles_y; // 8x8 tiles
     uint32_t rank, world;      // MODE_SHARD
     uint32_t tx, ty, blocks_x, blocks_y, win_bx, win_by, start_bx, start_by; // MODE_PARTIAL
+    uint32_t audit;           // wavefront pipeline: also run the filter audit kernel
     uint32_t max_shadow_rays; // shadow rays one diffuse hit casts: sum of shadowSamples over initialised area lights
 };
 

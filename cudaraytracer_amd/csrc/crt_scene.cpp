@@ -193,6 +193,17 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
             st(d.e23, sub(p[3], p[2]));
             st(d.e21, sub(p[1], p[2]));
             st(d.light_normal, cross(sub(w[1], w[0]), sub(w[3], w[0])));
+            {
+                double scale = 1e-30, dev = 0.0;
+                for (int k = 0; k < 3; ++k) {
+                    const double p0 = l.points[0][k], p1 = l.points[1][k], p2 = l.points[2][k], p3 = l.points[3][k];
+                    d.fB0[k] = (float)(p0 + (double)l.pos[k]);
+                    d.fB1[k] = (float)(p2 + (p3 - p2) + (p1 - p2) + (double)l.pos[k]);
+                    scale = fmax(scale, fmax(fmax(fabs(p0), fabs(p1)), fmax(fabs(p2), fabs(p3))));
+                    dev = fmax(dev, fabs((p1 - p0) + (p3 - p0) - (p2 - p0))); // p2 = p0 + e01 + e03 for a parallelogram
+                }
+                d.is_par = dev <= 1e-6 * scale ? 1u : 0u;
+            }
             QuadConst q = quad_constants(p[0], p[1], p[2], p[3]);
             st(d.nor, q.nor);
             fill_uv(d.uv, q);
@@ -227,8 +238,16 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
             b.lo[k] = -INFINITY;
             b.hi[k] = INFINITY;
         }
-        b.min_adn = INFINITY;
-        b.pad = 0.0f;
+        b.n2 = 0.0f;
+        b.sp_min2 = INFINITY;
+        if (i < in->n_geometry && in->geometry[i].kind == CRT_GEOM_QUAD && rabs > 0.0 && rabs < 1e6) {
+            const DevGeomHot& hq = out->hot[i];
+            const double n2 = (double)hq.n[0] * hq.n[0] + (double)hq.n[1] * hq.n[1] + (double)hq.n[2] * hq.n[2];
+            if (n2 > 1e-24 && n2 < 1e24) {
+                b.n2 = (float)n2;
+                b.sp_min2 = (float)(1e-8 * n2 * rabs * rabs);
+            }
+        }
         if (i >= in->n_geometry || in->geometry[i].kind != CRT_GEOM_QUAD || !out->uv[i].linear) continue;
         if (!(rabs > 0.0) || !(rabs < 1e6)) continue;
         const DevGeomHot& h = out->hot[i];
@@ -246,7 +265,6 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
             b.lo[k] = (float)(lo - margin);
             b.hi[k] = (float)(hi + margin);
         }
-        b.min_adn = (float)(0.01 * nlen);
     }
     const double dmax = 3.5 * rabs; // > 2*sqrt(3)*rabs: no two scene points are further apart
     for (uint32_t l = 0; l < CRT_MAX_LIGHTS; ++l)

@@ -48,8 +48,8 @@ struct alignas(16) DevGeomUV { // quad only (Quad.hpp:232-250): everything that 
 // of a non-parallelogram quad carry -inf/+inf, which never reject.
 struct alignas(32) DevGeomBox {
     float lo[3], hi[3];
-    float min_adn; // the box test is used only when |d . nor| exceeds this (0.01 |nor|: not grazing)
-    float pad;
+    float n2;      // |nor|^2
+    float sp_min2; // (1e-4 * |nor| * scene size)^2: a point this far off the plane is robustly off it
 };
 
 struct alignas(16) DevGeomShade {
@@ -77,6 +77,11 @@ struct alignas(64) DevLight {
     float e01[3], e03[3];  // points[1]-points[0], points[3]-points[0] (AreaLight.hpp:359)
     float e23[3], e21[3];  // points[3]-points[2], points[1]-points[2] (AreaLight.hpp:370)
     float light_normal[3]; // (pts[1]-pts[0]) x (pts[3]-pts[0]) (AreaLight.hpp:250)
+    // Shadow-ray filter only (approximate by design, see crt_wavefront.hip): the sample point is
+    // fB0 + e01 u + e03 v when u + v < 1 and fB1 - e23 u - e21 v otherwise; for a parallelogram the
+    // two agree and `is_par` is set.
+    float fB0[3], fB1[3];
+    uint32_t is_par;
     // _hittedLight (AreaLight.hpp:382-432), same derivation as a quad
     float nor[3];
     DevGeomUV uv;

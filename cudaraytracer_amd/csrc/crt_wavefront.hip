@@ -511,24 +511,34 @@ DI void stage_flush(const WfArgs& w, uint32_t (*stg)[kStageCap], Stage& st, uint
     __syncthreads();
 }
 
+// Conservative classification of NB shadow rays of one shaded point against the primitives in
+// `prim_mask`.  Nothing here reproduces the reference's rounding: every statement carries a margin
+// (1e-3 relative, or 2e-5 of ray length) that is orders of magnitude above the 1e-6 rounding of the
+// reference's own test, and every ray that is not decided with that margin is left undecided for
+// the exact test.  The ray is handled un-normalised: points P + s D, D = X - P towards the light
+// sample X, a = D.D.  The reference's ray starts at s0 = 0.01/|D| and ends at 1 + s0
+// (AreaLight.hpp:495-510: origin P + 0.01 dir, length |X - P|).
+//
+// Sphere, Lp = P - C, bq = D.Lp, c0 = Lp.Lp - r^2, e0 = Lp.Lp + r^2, disc = bq^2 - a c0
+// (= a^2/4 times the reference's discriminant, Sphere.hpp:56-63):
+//   free   disc < -margin (the line misses), or bq > 0 and c0 > 0 with margins (sphere behind the origin:
+//          b > 0, c > 0 in the reference, both roots negative, Sphere.hpp:85-96);
+//   sure   P further than 0.02 from the surface, disc > margin (so bq^2 > a c0 > 0 and bq is far from 0),
+//          bq < 0: both roots positive, the first is s1 = c0 / (-bq + sqrt(disc)) < c0 / -bq <= 0.999,
+//          i.e. before the light sample, and more than 0.01 beyond the ray origin.
+// Quad, sP = nor.(P - v0), dnq = nor.D; the reference's t = -(p.nor / d.nor) = -sP |D| / dnq - 0.01
+// (Quad.hpp:222-226):
+//   free   sP dnq > 0 with P robustly off the plane (t < 0);
+//          or |sP| |D| < 0.005 |dnq| and the ray not grazing (P on the plane: the 0.01 step decides, t < 0);
+//          or opposite signs and (|sP| - |dnq|) |D| > 0.01002 |dnq| (t > |D|);
+//          or the plane point P - (sP/dnq) D is outside the quad's bounding box (DevGeomBox).
+struct Classes {
+    uint32_t sure_opaque, maybe_any, maybe_glass; // bit j = ray j
+};
+
 template <int NB>
-DI void filter_block(const WfArgs& w, ScenePtr sc, const LightC& lc, uint64_t prim_mask, bool act, V3 P, Rng& rng,
-                     uint32_t key, uint32_t& shadowed, uint32_t (*stg)[kStageCap], Stage& st, uint32_t lane,
-                     uint32_t& tally) {
-    V3 o[NB], d[NB];
-    float x[NB], us[NB], vs[NB], dd4[NB];
-    bool ddok[NB], xok[NB];
-    uint32_t sure_opaque = 0, maybe_any = 0, maybe_glass = 0; // bit j = sample j of the block
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        us[j] = rng_uniform(rng);
-        vs[j] = rng_uniform(rng);
-        shadow_ray(lc, P, us[j], vs[j], o[j], d[j], x[j]);
-        const float dd = dot3(d[j], d[j]);
-        dd4[j] = 4.0f * dd; // 4.f * a (Sphere.hpp:61)
-        ddok[j] = dd > 1e-6f && dd < 1e6f;
-        xok[j] = x[j] > 1e-30f && x[j] < 1e30f;
-    }
+DI Classes classify_block(ScenePtr sc, uint64_t prim_mask, V3 P, const V3 (&D)[NB], const float (&a)[NB]) {
+    Classes k = {0u, 0u, 0u};
     uint64_t m = prim_mask;
     while (m != 0) {
         const uint32_t i = (uint32_t)__builtin_ctzll(m);
@@ -538,51 +548,124 @@ DI void filter_block(const WfArgs& w, ScenePtr sc, const LightC& lc, uint64_t pr
         const bool glass = g->mat_type == CRT_MAT_REFRACTIVE;
         const V3 go = ld3c(g->o), gn = ld3c(g->n);
         if (kind == CRT_GEOM_SPHERE) {
+            const float r2 = gn.x;
+            const V3 Lp = P - go;
+            const float l2 = __builtin_fmaf(Lp.x, Lp.x, __builtin_fmaf(Lp.y, Lp.y, Lp.z * Lp.z));
+            const float c0 = l2 - r2, e0 = l2 + r2;
+            // |Lp| > r + 0.02  <=>  c0 > 0.04 r + 4e-4; with r <= sqrt(e0): c0 > 0.04 sqrt(e0) + 4e-4 is sufficient,
+            // tested without the root as c0 > 5e-4 and (c0 - 4e-4)^2 > 1.6e-3 e0
+            const float cm = c0 - 4e-4f;
+            const bool outside = c0 > 5e-4f && cm * cm > 1.61e-3f * e0 && e0 < 1e12f;
+            const bool c_pos = c0 > 1e-3f * e0 && c0 > 1e-30f && e0 < 1e12f;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const uint32_t c = sphere_class(go, gn.x, o[j], d[j], dd4[j], ddok[j], x[j]);
-                if (glass) {
-                    if (c != 0u) {
-                        maybe_any |= 1u << j;
-                        maybe_glass |= 1u << j;
+                const float bq = __builtin_fmaf(D[j].x, Lp.x, __builtin_fmaf(D[j].y, Lp.y, D[j].z * Lp.z));
+                const float bq2 = bq * bq;
+                const float disc = __builtin_fmaf(-a[j], c0, bq2);
+                const float marg = 1e-3f * __builtin_fmaf(a[j], e0, bq2);
+                const bool a_ok = a[j] > 1e-6f && a[j] < 1e12f;
+                const bool free_ = a_ok && (disc < -marg || (c_pos && bq > 0.0f && bq2 > 1e-6f * (a[j] * e0)));
+                const bool sure = a_ok && outside && bq < 0.0f && disc > __builtin_fmaf(1e-4f, a[j], marg) &&
+                                  c0 < -bq * 0.999f;
+                if (!free_) {
+                    if (glass) {
+                        k.maybe_any |= 1u << j;
+                        k.maybe_glass |= 1u << j;
+                    } else if (sure) {
+                        k.sure_opaque |= 1u << j;
+                    } else {
+                        k.maybe_any |= 1u << j;
                     }
-                } else {
-                    if (c == 1u) maybe_any |= 1u << j;
-                    if (c == 2u) sure_opaque |= 1u << j;
                 }
             }
         } else {
             const DevGeomBox CRT_CONST* bx = &sc->box[i];
             const V3 blo = ld3c(bx->lo), bhi = ld3c(bx->hi);
-            const float min_adn = bx->min_adn;
+            const float n2 = bx->n2, sp_min2 = bx->sp_min2;
+            const V3 q = P - go;
+            const float sP = __builtin_fmaf(q.x, gn.x, __builtin_fmaf(q.y, gn.y, q.z * gn.z));
+            const float sP2 = sP * sP;
+            const bool off_plane = sP2 > sp_min2;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                float pn, dn;
-                if (kind == CRT_HOT_QUAD_X) {
-                    pn = (o[j].x - go.x) * gn.x;
-                    dn = d[j].x * gn.x;
-                } else if (kind == CRT_HOT_QUAD_Y) {
-                    pn = (o[j].y - go.y) * gn.y;
-                    dn = d[j].y * gn.y;
-                } else if (kind == CRT_HOT_QUAD_Z) {
-                    pn = (o[j].z - go.z) * gn.z;
-                    dn = d[j].z * gn.z;
-                } else {
-                    const V3 p = o[j] - go;
-                    pn = p.x * gn.x + p.y * gn.y + p.z * gn.z;
-                    dn = d[j].x * gn.x + d[j].y * gn.y + d[j].z * gn.z;
-                }
-                const bool h = plane_may_hit(pn, dn, x[j], xok[j]) && box_may_hit(blo, bhi, min_adn, o[j], d[j], pn, dn);
-                if (h) {
-                    maybe_any |= 1u << j;
-                    if (glass) maybe_glass |= 1u << j;
+                float dnq;
+                if (kind == CRT_HOT_QUAD_X) dnq = D[j].x * gn.x;
+                else if (kind == CRT_HOT_QUAD_Y) dnq = D[j].y * gn.y;
+                else if (kind == CRT_HOT_QUAD_Z) dnq = D[j].z * gn.z;
+                else dnq = __builtin_fmaf(D[j].x, gn.x, __builtin_fmaf(D[j].y, gn.y, D[j].z * gn.z));
+                const float dn2 = dnq * dnq;
+                const bool a_ok = a[j] > 1e-6f && a[j] < 1e12f;
+                const bool same = sP * dnq > 0.0f;
+                const bool behind = same && off_plane;
+                const bool lifted = sP2 * a[j] < 2.5e-5f * dn2 && dn2 > 4e-6f * (n2 * a[j]);
+                const float e = __builtin_fabsf(sP) - __builtin_fabsf(dnq) * 1.000004f;
+                const bool beyond = !same && off_plane && e > 0.0f && (e * e) * a[j] > 1.004004e-4f * dn2;
+                // plane point times dnq, against the box times |dnq|
+                const float ad = __builtin_fabsf(dnq);
+                const float sg = dnq < 0.0f ? -1.0f : 1.0f;
+                const float qx = __builtin_fmaf(P.x, dnq, -(sP * D[j].x)) * sg;
+                const float qy = __builtin_fmaf(P.y, dnq, -(sP * D[j].y)) * sg;
+                const float qz = __builtin_fmaf(P.z, dnq, -(sP * D[j].z)) * sg;
+                const bool outside = qx < blo.x * ad || qx > bhi.x * ad || qy < blo.y * ad || qy > bhi.y * ad ||
+                                     qz < blo.z * ad || qz > bhi.z * ad;
+                const bool boxed_out = outside && dn2 > 1e-4f * (n2 * a[j]);
+                const bool free_ = a_ok && (behind || lifted || beyond || boxed_out);
+                if (!free_) {
+                    k.maybe_any |= 1u << j;
+                    if (glass) k.maybe_glass |= 1u << j;
                 }
             }
         }
     }
+    return k;
+}
+
+// Light-sample offsets D = X - P for the filter (approximate: fused operations, the second triangle
+// folded algebraically; the exact sample point is rebuilt from (u, v) by whoever needs it).
+struct LightF {
+    V3 B0, B1, e01, e03, e23, e21;
+    bool is_par;
+};
+DI LightF load_lightf(const DevLight CRT_CONST* L) {
+    LightF f;
+    f.B0 = ld3c(L->fB0);
+    f.B1 = ld3c(L->fB1);
+    f.e01 = ld3c(L->e01);
+    f.e03 = ld3c(L->e03);
+    f.e23 = ld3c(L->e23);
+    f.e21 = ld3c(L->e21);
+    f.is_par = L->is_par != 0u;
+    return f;
+}
+DI V3 sample_offset(const LightF& lf, V3 Bp0, V3 Bp1, float u, float v) {
+    V3 D = mk3(__builtin_fmaf(lf.e03.x, v, __builtin_fmaf(lf.e01.x, u, Bp0.x)),
+               __builtin_fmaf(lf.e03.y, v, __builtin_fmaf(lf.e01.y, u, Bp0.y)),
+               __builtin_fmaf(lf.e03.z, v, __builtin_fmaf(lf.e01.z, u, Bp0.z)));
+    if (!lf.is_par && !(u + v < 1.0f)) {
+        D = mk3(__builtin_fmaf(-lf.e21.x, v, __builtin_fmaf(-lf.e23.x, u, Bp1.x)),
+                __builtin_fmaf(-lf.e21.y, v, __builtin_fmaf(-lf.e23.y, u, Bp1.y)),
+                __builtin_fmaf(-lf.e21.z, v, __builtin_fmaf(-lf.e23.z, u, Bp1.z)));
+    }
+    return D;
+}
+
+template <int NB>
+DI void filter_block(const WfArgs& w, ScenePtr sc, const LightF& lf, uint64_t prim_mask, bool act, V3 P, V3 Bp0, V3 Bp1,
+                     Rng& rng, uint32_t key, uint32_t& shadowed, uint32_t (*stg)[kStageCap], Stage& st, uint32_t lane,
+                     uint32_t& tally) {
+    V3 D[NB];
+    float a[NB], us[NB], vs[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const bool so = (sure_opaque >> j) & 1u, ma = (maybe_any >> j) & 1u, mg = (maybe_glass >> j) & 1u;
+        us[j] = rng_uniform(rng);
+        vs[j] = rng_uniform(rng);
+        D[j] = sample_offset(lf, Bp0, Bp1, us[j], vs[j]);
+        a[j] = __builtin_fmaf(D[j].x, D[j].x, __builtin_fmaf(D[j].y, D[j].y, D[j].z * D[j].z));
+    }
+    const Classes k = classify_block<NB>(sc, prim_mask, P, D, a);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const bool so = (k.sure_opaque >> j) & 1u, ma = (k.maybe_any >> j) & 1u, mg = (k.maybe_glass >> j) & 1u;
         const bool covered = act && so && !mg; // the closest hit is opaque whichever primitive it is
         const bool unresolved = act && !covered && (ma || so);
         if (covered) ++shadowed;
@@ -629,7 +712,8 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
             const DevLight CRT_CONST* L = &sc->lights[li];
             if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue; // no draws (Light.hpp:92-111, AreaLight.hpp:586)
             const uint32_t S = L->shadow_samples;
-            const LightC lc = load_lightc(L);
+            const LightF lf = load_lightf(L);
+            const V3 Bp0 = lf.B0 - P, Bp1 = lf.B1 - P;
             // primitives that may stop a shadow ray of some record of this wave
             uint64_t prim_mask = 0;
             for (uint32_t i = 0; i < n_geom; ++i) {
@@ -646,14 +730,102 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
             const uint32_t key = wi | (li << 28);
             uint32_t s = 0;
             for (; s + 5u <= S; s += 5u)
-                filter_block<5>(w, sc, lc, prim_mask, act, P, rng, key, shadowed, stg, st, lane, tally);
-            for (; s < S; ++s) filter_block<1>(w, sc, lc, prim_mask, act, P, rng, key, shadowed, stg, st, lane, tally);
+                filter_block<5>(w, sc, lf, prim_mask, act, P, Bp0, Bp1, rng, key, shadowed, stg, st, lane, tally);
+            for (; s < S; ++s) filter_block<1>(w, sc, lf, prim_mask, act, P, Bp0, Bp1, rng, key, shadowed, stg, st, lane, tally);
             if (act) w.shadow_cnt[(size_t)li * cw + wi] = shadowed;
         }
     }
     if (st.fill != 0u) stage_flush(w, stg, st, st.fill, lane);
     if (lane == 0) w.qcounts[blockIdx.x] = st.written;
     if (lane == 0 && tally != 0u) atomicAdd(&w.r.wave_tallies[0], (unsigned long long)tally);
+}
+
+// ---------------------------------------------------------------------------------------- audit
+// Test instrument: repeats the filter's classification for every shadow ray of the records in
+// [w_begin, w_end) and compares each decided ray with the exact test.  tallies[2] += decided rays,
+// tallies[3] += contradictions (must stay 0).
+__global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end) {
+    ScenePtr sc = (ScenePtr)w.r.scene;
+    const uint32_t lane = threadIdx.x;
+    const size_t cw = w.cap_work;
+    const uint32_t n_geom = sc->n_geom, n_lights = sc->n_lights;
+    unsigned long long decided = 0, bad = 0;
+    for (uint32_t base = blockIdx.x * 64u; base < w_end - w_begin; base += gridDim.x * 64u) {
+        const uint32_t wi = w_begin + base + lane;
+        const uint32_t wr = wi < w_end ? wi : w_begin;
+        const bool act = wi < w_end && w.work[(size_t)WK_GEOM * cw + wr] != kNoRecord;
+        const uint32_t* r = w.work + wr;
+        const V3 P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
+        Rng rng;
+        rng.v0 = r[(WK_RNG + 0) * cw];
+        rng.v1 = r[(WK_RNG + 1) * cw];
+        rng.v2 = r[(WK_RNG + 2) * cw];
+        rng.v3 = r[(WK_RNG + 3) * cw];
+        rng.v4 = r[(WK_RNG + 4) * cw];
+        rng.d = r[(WK_RNG + 5) * cw];
+        for (uint32_t li = 0; li < n_lights; ++li) {
+            const DevLight CRT_CONST* L = &sc->lights[li];
+            if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue;
+            const uint32_t S = L->shadow_samples;
+            const LightF lf = load_lightf(L);
+            const LightC lc = load_lightc(L);
+            const V3 Bp0 = lf.B0 - P, Bp1 = lf.B1 - P;
+            uint64_t prim_mask = 0;
+            for (uint32_t i = 0; i < n_geom; ++i) {
+                const DevGeomHot CRT_CONST* g = &sc->hot[i];
+                bool keep = true;
+                if (g->kind != CRT_GEOM_SPHERE) {
+                    const V3 q = P - ld3c(g->o);
+                    const float s = (q.x * g->n[0] + q.y * g->n[1]) + q.z * g->n[2];
+                    keep = !(s * sc->cull_side[li][i] > sc->cull_thr[li][i]);
+                }
+                if (keep) prim_mask |= 1ull << i;
+            }
+            // per lane: the primitives this record did not cull (the filter uses the union over the wave,
+            // which can only add tests)
+            for (uint32_t s = 0; s < S; ++s) {
+                const float u = rng_uniform(rng), v = rng_uniform(rng);
+                V3 D[1];
+                float a[1];
+                D[0] = sample_offset(lf, Bp0, Bp1, u, v);
+                a[0] = __builtin_fmaf(D[0].x, D[0].x, __builtin_fmaf(D[0].y, D[0].y, D[0].z * D[0].z));
+                Classes k = {0u, 0u, 0u};
+                // classify_block wants a wave-uniform mask: walk the union, apply this lane's bit
+                uint64_t un = 0;
+                for (uint32_t i = 0; i < n_geom; ++i)
+                    if (__any((prim_mask >> i) & 1ull)) un |= 1ull << i;
+                for (uint64_t m = un; m != 0; m &= m - 1u) {
+                    const uint32_t i = (uint32_t)__builtin_ctzll(m);
+                    const Classes one = classify_block<1>(sc, 1ull << i, P, D, a);
+                    if ((prim_mask >> i) & 1ull) {
+                        k.sure_opaque |= one.sure_opaque;
+                        k.maybe_any |= one.maybe_any;
+                        k.maybe_glass |= one.maybe_glass;
+                    }
+                }
+                const bool covered = k.sure_opaque && !k.maybe_glass;
+                const bool unresolved = !covered && (k.maybe_any || k.sure_opaque);
+                if (act && !unresolved) {
+                    V3 o, d;
+                    float x;
+                    shadow_ray(lc, P, u, v, o, d, x);
+                    const Hit h = closest_hit(sc, o, d, x);
+                    const bool exact_opaque = h.idx >= 0 && h.mat_type != CRT_MAT_REFRACTIVE;
+                    const bool exact_free = h.idx < 0;
+                    ++decided;
+                    if (covered ? !exact_opaque : !exact_free) ++bad;
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        decided += __shfl_down(decided, off, 64);
+        bad += __shfl_down(bad, off, 64);
+    }
+    if (lane == 0) {
+        atomicAdd(&w.r.wave_tallies[2], decided);
+        atomicAdd(&w.r.wave_tallies[3], bad);
+    }
 }
 
 // -------------------------------------------------------------------------------------- resolve
@@ -934,6 +1106,7 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
             const uint32_t groups = (b1 - b0 + 63u) / 64u;
             const uint32_t fgrid = groups < fwaves ? groups : fwaves;
             hipLaunchKernelGGL(wf_filter_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
+            if (args.audit) hipLaunchKernelGGL(wf_audit_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
             hipLaunchKernelGGL(wf_resolve_kernel, dim3(fgrid), dim3(64), 0, stream, w);
         }
         if (n_work != 0u)

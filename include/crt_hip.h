@@ -221,6 +221,13 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out);
 #define CRT_PIPELINE_PERSISTENT 1
 #define CRT_PIPELINE_WAVEFRONT 2
 int crt_set_pipeline(crt_ctx* ctx, int pipeline);
+/* Test instrument of the wavefront pipeline.  Its filter kernel decides most shadow rays ("free" or
+ * "blocked by an opaque primitive") with conservative tests and sends the rest to the exact test.
+ * With the audit enabled every decided ray is also put through the exact test
+ * (Light::_isCovered, Light.hpp:35-86) and contradictions are counted; crt_audit_result returns the
+ * totals since the last crt_rng_init.  A correct build reports 0 contradictions.  Slow; off by default. */
+int crt_set_audit(crt_ctx* ctx, int enabled);
+int crt_audit_result(crt_ctx* ctx, uint64_t* checked, uint64_t* contradictions);
 /* Upper bound in bytes of the wavefront pipeline's device workspace (default 32 GiB); a smaller
  * bound means more rounds per image, never a different image.  No counterpart in the reference. */
 int crt_set_workspace_limit(crt_ctx* ctx, size_t bytes);

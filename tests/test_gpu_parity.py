@@ -250,3 +250,66 @@ def test_full_size_gl1_properties(gpu_ctx, oracle):
     assert np.array_equal(a[y0:y0 + 16, x0:x0 + 24], ref[y0:y0 + 16, x0:x0 + 24])
     idx = (np.arange(y0, y0 + 16)[:, None] * 720 + np.arange(x0, x0 + 24)[None, :]).reshape(-1)
     assert np.array_equal(sa[idx], ref_state[idx])
+
+
+# ------------------------------------------------------------------ wavefront pipeline specifics
+def _wavefront_ctx():
+    from cudaraytracer_amd import abi
+    ctx = crt.Context(0)
+    ctx.set_pipeline(abi.CRT_PIPELINE_WAVEFRONT)
+    return ctx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,aa,gl,ind,S", [(24, 1, 1, 75, 50), (12, 1, 2, 9, 7), (16, 0, 3, 3, 4)])
+def test_wavefront_rounds_with_a_tiny_workspace(oracle, n, aa, gl, ind, S):
+    """A 1 MiB workspace limit forces the minimum quota (16 result slots per pixel and round), so the
+    traversal is parked and resumed many times; the image and RNG end states must not change."""
+    ctx = _wavefront_ctx()
+    try:
+        ctx.set_workspace_limit(1 << 20)
+        st = crt.make_settings(nx=n, ny=n, aa_iter=aa, gl_iter=gl, ind_rays=ind, shadowSamples=S)
+        scene = crt.cornell_box(S)
+        fb, state = _gpu_render(ctx, scene, st, 99)
+        ref, _, ref_state = oracle.render(oracle.cornell(S), st, 99, want_state=True)
+        assert np.array_equal(fb, ref)
+        assert np.array_equal(state, ref_state)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_wavefront_rejects_adaptive_aa_when_forced():
+    ctx = _wavefront_ctx()
+    try:
+        st = crt.make_settings(nx=8, ny=8, aa_iter=2, gl_iter=0)
+        ctx.upload(crt.cornell_box(4))
+        ctx.rng_init(8, 8, 1)
+        with pytest.raises(crt.CrtError):
+            ctx.render_to_host(st)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cornell", "point_light", "two_lights_two_sided", "skewed_quads", "uninitialised_area_light"])
+def test_filter_decisions_agree_with_the_exact_test(kind):
+    """Audit: every shadow ray the conservative filter decides is also run through the exact
+    closest-hit test; no contradiction is allowed."""
+    ctx = _wavefront_ctx()
+    try:
+        ctx.set_audit(True)
+        if kind == "cornell":
+            scene, st = crt.cornell_box(50), crt.make_settings(nx=96, ny=96, aa_iter=1, gl_iter=1, ind_rays=20)
+        else:
+            scene = _custom_scene(crt, kind)
+            st = crt.make_settings(nx=40, ny=40, aa_iter=1, gl_iter=1, ind_rays=6, shadowSamples=9)
+        ctx.upload(scene)
+        ctx.rng_init(st.nx, st.ny, 7)
+        ctx.render_to_host(st)
+        checked, bad = ctx.audit_result()
+        assert bad == 0
+        if kind not in ("point_light", "uninitialised_area_light"):
+            assert checked > 0
+    finally:
+        ctx.close()
