@@ -41,6 +41,7 @@ struct WfWorkspace {
     uint32_t cap_work = 0;  // shade records per round
     uint32_t n_lights = 0;  // shadow-count planes
     uint32_t qcap = 0;      // unresolved shadow rays per filter batch
+    uint32_t max_shadow_rays = 0; // shadow rays per record the queue was sized for
     uint32_t* ctrs = nullptr;       // device counters (WF_CTR_*), 64 words
     uint32_t* ctrs_host = nullptr;  // pinned mirror
     uint32_t* state = nullptr;      // [WF_STATE_PLANES][n_lp] traversal state between rounds

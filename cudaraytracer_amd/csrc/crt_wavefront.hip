@@ -685,7 +685,7 @@ DI void filter_block(const WfArgs& w, ScenePtr sc, const LightF& lf, uint64_t pr
 }
 
 #ifndef CRT_WF_FILTER_WAVES
-#define CRT_WF_FILTER_WAVES 6
+#define CRT_WF_FILTER_WAVES 8
 #endif
 __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end) {
     ScenePtr sc = (ScenePtr)w.r.scene;
@@ -998,13 +998,19 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     }
     const uint32_t quota = (uint32_t)want;
     const uint32_t levels = args.gl_iter ? args.gl_iter : 1u;
-    if (ws.n_lp == n_lp && ws.quota >= quota && ws.gl_levels >= levels && ws.n_lights >= lights) return hipSuccess;
+    if (ws.n_lp == n_lp && ws.quota >= quota && ws.gl_levels >= levels && ws.n_lights >= lights &&
+        ws.max_shadow_rays >= args.max_shadow_rays)
+        return hipSuccess;
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return e;
     wavefront_release(ws);
     const uint32_t cap_work = quota * n_lp + args.n_units * kWorkChunk; // + every trace wave's partly used chunk
-    // every filter wave owns a region of the queue that holds all shadow rays of its records; 2^28 rays (3.2 GB)
-    const uint32_t qcap = 1u << 28;
+    // every filter wave owns a region of the queue that holds all shadow rays of its records:
+    // at most 2^30 rays (12.9 GB), less when all records of a round cast fewer
+    uint64_t qwant = (uint64_t)cap_work * (args.max_shadow_rays ? args.max_shadow_rays : 1u) + 64ull * kMaxFilterWaves;
+    if (qwant > (1ull << 30)) qwant = 1ull << 30;
+    if (qwant < (1ull << 20)) qwant = 1ull << 20;
+    const uint32_t qcap = (uint32_t)qwant;
     size_t total = 0;
     auto grab = [&](void** p, size_t bytes) {
         if (e != hipSuccess) return;
@@ -1033,6 +1039,7 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     ws.cap_work = cap_work;
     ws.n_lights = lights;
     ws.qcap = qcap;
+    ws.max_shadow_rays = args.max_shadow_rays;
     ws.bytes = total;
     return hipSuccess;
 }
