@@ -203,6 +203,15 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
                     dev = fmax(dev, fabs((p1 - p0) + (p3 - p0) - (p2 - p0))); // p2 = p0 + e01 + e03 for a parallelogram
                 }
                 d.is_par = dev <= 1e-6 * scale ? 1u : 0u;
+                double g11 = 0, g12 = 0, g22 = 0;
+                for (int k = 0; k < 3; ++k) {
+                    g11 += (double)d.e01[k] * d.e01[k];
+                    g12 += (double)d.e01[k] * d.e03[k];
+                    g22 += (double)d.e03[k] * d.e03[k];
+                }
+                d.fg[0] = (float)g11;
+                d.fg[1] = (float)(2.0 * g12);
+                d.fg[2] = (float)g22;
             }
             QuadConst q = quad_constants(p[0], p[1], p[2], p[3]);
             st(d.nor, q.nor);
@@ -291,7 +300,7 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
             if (smin > need) { side = 1.0; near = smin; }
             else if (smax < -need) { side = -1.0; near = -smax; }
             else continue;
-            const double noise = 1e-5 * nlen * rabs;
+            const double noise = 2e-6 * nlen * rabs; // 4x the rounding of p.nor for |p| <= 2 sqrt(3) rabs
             const double theta = 0.5 * 0.01 * near / dmax - noise; // P may be this far on the wrong side of the plane
             out->cull_side[l][i] = (float)side;
             out->cull_thr[l][i] = (float)(-theta) + (theta < 0 ? 1e-30f : 0.0f);

@@ -82,6 +82,7 @@ struct alignas(64) DevLight {
     // two agree and `is_par` is set.
     float fB0[3], fB1[3];
     uint32_t is_par;
+    float fg[3]; // e01.e01, 2 e01.e03, e03.e03
     // _hittedLight (AreaLight.hpp:382-432), same derivation as a quad
     float nor[3];
     DevGeomUV uv;

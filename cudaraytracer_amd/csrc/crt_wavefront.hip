@@ -624,6 +624,8 @@ DI Classes classify_block(ScenePtr sc, uint64_t prim_mask, V3 P, const V3 (&D)[N
 // folded algebraically; the exact sample point is rebuilt from (u, v) by whoever needs it).
 struct LightF {
     V3 B0, B1, e01, e03, e23, e21;
+    float g11, g12x2, g22; // |e01|^2, 2 e01.e03, |e03|^2
+    V3 nor;                // the light's plane normal (un-normalised)
     bool is_par;
 };
 DI LightF load_lightf(const DevLight CRT_CONST* L) {
@@ -634,6 +636,10 @@ DI LightF load_lightf(const DevLight CRT_CONST* L) {
     f.e03 = ld3c(L->e03);
     f.e23 = ld3c(L->e23);
     f.e21 = ld3c(L->e21);
+    f.g11 = L->fg[0];
+    f.g12x2 = L->fg[1];
+    f.g22 = L->fg[2];
+    f.nor = ld3c(L->nor);
     f.is_par = L->is_par != 0u;
     return f;
 }
@@ -648,21 +654,264 @@ DI V3 sample_offset(const LightF& lf, V3 Bp0, V3 Bp1, float u, float v) {
     }
     return D;
 }
+DI float fdot(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
 
-template <int NB>
-DI void filter_block(const WfArgs& w, ScenePtr sc, const LightF& lf, uint64_t prim_mask, bool act, V3 P, V3 Bp0, V3 Bp1,
-                     Rng& rng, uint32_t key, uint32_t& shadowed, uint32_t (*stg)[kStageCap], Stage& st, uint32_t lane,
+// For a parallelogram light D = Bp + e01 u + e03 v is affine in the two draws, so every quantity the
+// classification needs is a polynomial in (u, v) whose coefficients depend only on the shaded point:
+//   a  = D.D    = h0 + 2h1 u + 2h2 v + g11 u^2 + 2g12 uv + g22 v^2
+//   bq = D.Lp   = b0 + b1 u + b2 v
+//   disc = bq^2 - a c0 = A u^2 + B uv + C v^2 + Du u + Ev v + F
+//   dnq = nor.D = d0 + d1 u + d2 v,   plane point times dnq:  q_k = qk0 + qk1 u + qk2 v
+// Two spheres and one quad of the wave's candidate set get such coefficient sets ("slots") per lane;
+// further candidates take the generic path (classify_block).  The per-sample margins of
+// classify_block are replaced by their maxima over the light (a_max, max bq^2: both are attained at
+// corners), which only widens the undecided band.
+struct SphSlot {
+    float A, B, C, Du, Ev, F, b0, b1, b2;
+    float M;  // free:  disc < -M
+    float M2; // sure:  disc > M2  (+inf when the point is not clearly outside the sphere)
+    float kb; // free:  bq > kb    (+inf unless c0 is clearly positive)
+    float kc; // sure:  bq < -kc
+};
+struct QuadSlot {
+    float sP, d0, d1, d2;
+    float q[3][3]; // [axis][1, u, v]
+    bool offp;
+};
+struct PolyA {
+    float h0, h1x2, h2x2;
+};
+
+DI SphSlot make_sph_slot(V3 P, V3 center, float r2, V3 Bp, const LightF& lf, const PolyA& pa, float a_max) {
+    SphSlot s;
+    const V3 Lp = P - center;
+    const float l2 = fdot(Lp, Lp);
+    const float c0 = l2 - r2, e0 = l2 + r2;
+    s.b0 = fdot(Bp, Lp);
+    s.b1 = fdot(lf.e01, Lp);
+    s.b2 = fdot(lf.e03, Lp);
+    s.A = __builtin_fmaf(s.b1, s.b1, -(c0 * lf.g11));
+    s.B = __builtin_fmaf(2.0f * s.b1, s.b2, -(c0 * lf.g12x2));
+    s.C = __builtin_fmaf(s.b2, s.b2, -(c0 * lf.g22));
+    s.Du = __builtin_fmaf(2.0f * s.b0, s.b1, -(c0 * pa.h1x2));
+    s.Ev = __builtin_fmaf(2.0f * s.b0, s.b2, -(c0 * pa.h2x2));
+    s.F = __builtin_fmaf(s.b0, s.b0, -(c0 * pa.h0));
+    const float q00 = s.b0, q10 = s.b0 + s.b1, q01 = s.b0 + s.b2, q11 = q10 + s.b2;
+    const float bqmax2 = __builtin_fmaxf(__builtin_fmaxf(q00 * q00, q10 * q10), __builtin_fmaxf(q01 * q01, q11 * q11));
+    s.M = 1e-3f * __builtin_fmaf(a_max, e0, bqmax2);
+    const float cm = c0 - 4e-4f;
+    const bool outside = c0 > 5e-4f && cm * cm > 1.61e-3f * e0 && e0 < 1e12f; // further than 0.02 from the surface
+    const bool c_pos = c0 > 1e-3f * e0 && c0 > 1e-30f && e0 < 1e12f;
+    s.M2 = outside ? __builtin_fmaf(1e-4f, a_max, s.M) : __builtin_inff();
+    s.kb = c_pos ? __builtin_sqrtf(1e-6f * (a_max * e0)) * 1.001f : __builtin_inff();
+    s.kc = c0 * 1.0011f;
+    return s;
+}
+// returns 0 free, 1 undecided, 2 sure
+DI uint32_t sph_slot_class(const SphSlot& s, float u, float v) {
+    const float bq = __builtin_fmaf(s.b2, v, __builtin_fmaf(s.b1, u, s.b0));
+    const float t1 = __builtin_fmaf(s.A, u, __builtin_fmaf(s.B, v, s.Du));
+    const float t2 = __builtin_fmaf(s.C, v, s.Ev);
+    const float disc = __builtin_fmaf(t1, u, __builtin_fmaf(t2, v, s.F));
+    if (disc < -s.M || bq > s.kb) return 0u;
+    return (disc > s.M2 && bq < -s.kc) ? 2u : 1u;
+}
+
+DI QuadSlot make_quad_slot(V3 P, V3 v0, V3 nor, float sp_min2, V3 Bp, const LightF& lf) {
+    QuadSlot q;
+    const V3 pq = P - v0;
+    q.sP = fdot(pq, nor);
+    q.offp = q.sP * q.sP > sp_min2;
+    q.d0 = fdot(nor, Bp);
+    q.d1 = fdot(nor, lf.e01);
+    q.d2 = fdot(nor, lf.e03);
+    const float Pk[3] = {P.x, P.y, P.z}, Bk[3] = {Bp.x, Bp.y, Bp.z}, e1[3] = {lf.e01.x, lf.e01.y, lf.e01.z},
+                e3[3] = {lf.e03.x, lf.e03.y, lf.e03.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        q.q[k][0] = __builtin_fmaf(Pk[k], q.d0, -(q.sP * Bk[k]));
+        q.q[k][1] = __builtin_fmaf(Pk[k], q.d1, -(q.sP * e1[k]));
+        q.q[k][2] = __builtin_fmaf(Pk[k], q.d2, -(q.sP * e3[k]));
+    }
+    return q;
+}
+// true: free for sure (same statements as the quad part of classify_block)
+DI bool quad_slot_free(const QuadSlot& q, V3 blo, V3 bhi, float n2, const PolyA& pa, const LightF& lf, float u, float v) {
+    const float dnq = __builtin_fmaf(q.d2, v, __builtin_fmaf(q.d1, u, q.d0));
+    const float a = __builtin_fmaf(__builtin_fmaf(lf.g11, u, __builtin_fmaf(lf.g12x2, v, pa.h1x2)), u,
+                                   __builtin_fmaf(__builtin_fmaf(lf.g22, v, pa.h2x2), v, pa.h0));
+    const float dn2 = dnq * dnq, sP2 = q.sP * q.sP;
+    const bool same = q.sP * dnq > 0.0f;
+    const bool behind = same && q.offp;
+    const bool lifted = sP2 * a < 2.5e-5f * dn2 && dn2 > 4e-6f * (n2 * a);
+    const float e = __builtin_fabsf(q.sP) - __builtin_fabsf(dnq) * 1.000004f;
+    const bool beyond = !same && q.offp && e > 0.0f && (e * e) * a > 1.004004e-4f * dn2;
+    const float ad = __builtin_fabsf(dnq);
+    const float sg = dnq < 0.0f ? -1.0f : 1.0f;
+    const float qx = __builtin_fmaf(q.q[0][2], v, __builtin_fmaf(q.q[0][1], u, q.q[0][0])) * sg;
+    const float qy = __builtin_fmaf(q.q[1][2], v, __builtin_fmaf(q.q[1][1], u, q.q[1][0])) * sg;
+    const float qz = __builtin_fmaf(q.q[2][2], v, __builtin_fmaf(q.q[2][1], u, q.q[2][0])) * sg;
+    const bool outside = qx < blo.x * ad || qx > bhi.x * ad || qy < blo.y * ad || qy > bhi.y * ad || qz < blo.z * ad ||
+                         qz > bhi.z * ad;
+    const bool boxed_out = outside && dn2 > 1e-4f * (n2 * a);
+    return behind || lifted || beyond || boxed_out;
+}
+
+// Everything the filter derives once per (shaded point, light) before its sample loop.
+struct RecordFilter {
+    // wave-uniform
+    bool poly;
+    int sph_i[2], quad_i;
+    bool sph_glass[2], quad_glass;
+    V3 blo, bhi;
+    float n2;
+    uint64_t rest_mask;
+    // per lane
+    bool rec_ok;
+    V3 P, Bp0, Bp1;
+    PolyA pa;
+    SphSlot s[2];
+    QuadSlot q;
+};
+
+DI RecordFilter make_record_filter(ScenePtr sc, uint32_t li, const LightF& lf, V3 P) {
+    RecordFilter f;
+    f.P = P;
+    f.Bp0 = lf.B0 - P;
+    f.Bp1 = lf.B1 - P;
+    // primitives that may stop a shadow ray of some record of this wave
+    uint64_t prim_mask = 0;
+    const uint32_t n_geom = sc->n_geom;
+    for (uint32_t i = 0; i < n_geom; ++i) {
+        const DevGeomHot CRT_CONST* g = &sc->hot[i];
+        bool keep = true;
+        if (g->kind != CRT_GEOM_SPHERE) {
+            const V3 q = P - ld3c(g->o);
+            const float s = (q.x * g->n[0] + q.y * g->n[1]) + q.z * g->n[2];
+            keep = !(s * sc->cull_side[li][i] > sc->cull_thr[li][i]);
+        }
+        if (__any(keep)) prim_mask |= 1ull << i;
+    }
+    f.poly = lf.is_par;
+    f.sph_i[0] = f.sph_i[1] = f.quad_i = -1;
+    f.sph_glass[0] = f.sph_glass[1] = f.quad_glass = false;
+    f.blo = f.bhi = mk3(0, 0, 0);
+    f.n2 = 0.0f;
+    f.rest_mask = prim_mask;
+    f.rec_ok = true;
+    f.pa.h0 = f.pa.h1x2 = f.pa.h2x2 = 0.0f;
+    if (!f.poly) return f;
+    // a(u,v) and its range over the light
+    f.pa.h0 = fdot(f.Bp0, f.Bp0);
+    f.pa.h1x2 = 2.0f * fdot(f.Bp0, lf.e01);
+    f.pa.h2x2 = 2.0f * fdot(f.Bp0, lf.e03);
+    const float a10 = f.pa.h0 + f.pa.h1x2 + lf.g11, a01 = f.pa.h0 + f.pa.h2x2 + lf.g22;
+    const float a11 = a10 + f.pa.h2x2 + lf.g22 + lf.g12x2;
+    const float a_max = __builtin_fmaxf(__builtin_fmaxf(f.pa.h0, a10), __builtin_fmaxf(a01, a11));
+    // |D| >= distance to the light's plane; the statements below need |D| > 1e-3
+    const float pl = fdot(lf.nor, f.Bp0);
+    const float nl2 = fdot(lf.nor, lf.nor);
+    f.rec_ok = pl * pl > 1.0001e-6f * nl2 && a_max < 1e12f && nl2 > 1e-30f && nl2 < 1e30f;
+    // slot assignment (wave-uniform): the first two spheres and the first quad of the candidate set
+    int i0 = -1, i1 = -1, iq = -1;
+    for (uint64_t m = prim_mask; m != 0; m &= m - 1u) {
+        const int i = __builtin_ctzll(m);
+        if (sc->hot[i].kind == CRT_GEOM_SPHERE) {
+            if (i0 < 0) i0 = i;
+            else if (i1 < 0) i1 = i;
+        } else if (iq < 0) {
+            iq = i;
+        }
+    }
+    if (i0 >= 0) {
+        const DevGeomHot CRT_CONST* g = &sc->hot[i0];
+        f.s[0] = make_sph_slot(P, ld3c(g->o), g->n[0], f.Bp0, lf, f.pa, a_max);
+        f.sph_i[0] = i0;
+        f.sph_glass[0] = g->mat_type == CRT_MAT_REFRACTIVE;
+        f.rest_mask &= ~(1ull << i0);
+    }
+    if (i1 >= 0) {
+        const DevGeomHot CRT_CONST* g = &sc->hot[i1];
+        f.s[1] = make_sph_slot(P, ld3c(g->o), g->n[0], f.Bp0, lf, f.pa, a_max);
+        f.sph_i[1] = i1;
+        f.sph_glass[1] = g->mat_type == CRT_MAT_REFRACTIVE;
+        f.rest_mask &= ~(1ull << i1);
+    }
+    if (iq >= 0) {
+        const DevGeomHot CRT_CONST* g = &sc->hot[iq];
+        const DevGeomBox CRT_CONST* bx = &sc->box[iq];
+        f.q = make_quad_slot(P, ld3c(g->o), ld3c(g->n), bx->sp_min2, f.Bp0, lf);
+        f.blo = ld3c(bx->lo);
+        f.bhi = ld3c(bx->hi);
+        f.n2 = bx->n2;
+        f.quad_i = iq;
+        f.quad_glass = g->mat_type == CRT_MAT_REFRACTIVE;
+        f.rest_mask &= ~(1ull << iq);
+    }
+    return f;
+}
+
+// SLOTS_ONLY: the caller has checked (wave-uniformly) that f.poly holds and f.rest_mask is empty.
+template <int NB, bool SLOTS_ONLY>
+DI Classes classify_samples(ScenePtr sc, const LightF& lf, const RecordFilter& f, const float (&us)[NB],
+                            const float (&vs)[NB]) {
+    Classes k = {0u, 0u, 0u};
+    if (!SLOTS_ONLY && f.rest_mask != 0) {
+        V3 D[NB];
+        float a[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            D[j] = sample_offset(lf, f.Bp0, f.Bp1, us[j], vs[j]);
+            a[j] = fdot(D[j], D[j]);
+        }
+        k = classify_block<NB>(sc, f.rest_mask, f.P, D, a);
+    }
+    if (SLOTS_ONLY || f.poly) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            if (f.sph_i[n] < 0) continue;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const uint32_t c = sph_slot_class(f.s[n], us[j], vs[j]);
+                if (f.sph_glass[n]) {
+                    if (c != 0u) {
+                        k.maybe_any |= 1u << j;
+                        k.maybe_glass |= 1u << j;
+                    }
+                } else {
+                    if (c == 1u) k.maybe_any |= 1u << j;
+                    if (c == 2u) k.sure_opaque |= 1u << j;
+                }
+            }
+        }
+        if (f.quad_i >= 0) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (!quad_slot_free(f.q, f.blo, f.bhi, f.n2, f.pa, lf, us[j], vs[j])) {
+                    k.maybe_any |= 1u << j;
+                    if (f.quad_glass) k.maybe_glass |= 1u << j;
+                }
+            }
+        }
+        if (!f.rec_ok) { // the shaded point is (almost) in the light's plane: decide nothing
+            k.maybe_any = (1u << NB) - 1u;
+            k.sure_opaque = 0u;
+        }
+    }
+    return k;
+}
+
+template <int NB, bool SLOTS_ONLY>
+DI void filter_block(const WfArgs& w, ScenePtr sc, const LightF& lf, const RecordFilter& f, bool act, Rng& rng,
+                     uint32_t key, uint32_t& shadowed, uint32_t (*stg)[kStageCap], Stage& st, uint32_t lane,
                      uint32_t& tally) {
-    V3 D[NB];
-    float a[NB], us[NB], vs[NB];
+    float us[NB], vs[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         us[j] = rng_uniform(rng);
         vs[j] = rng_uniform(rng);
-        D[j] = sample_offset(lf, Bp0, Bp1, us[j], vs[j]);
-        a[j] = __builtin_fmaf(D[j].x, D[j].x, __builtin_fmaf(D[j].y, D[j].y, D[j].z * D[j].z));
     }
-    const Classes k = classify_block<NB>(sc, prim_mask, P, D, a);
+    const Classes k = classify_samples<NB, SLOTS_ONLY>(sc, lf, f, us, vs);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const bool so = (k.sure_opaque >> j) & 1u, ma = (k.maybe_any >> j) & 1u, mg = (k.maybe_glass >> j) & 1u;
@@ -685,7 +934,7 @@ DI void filter_block(const WfArgs& w, ScenePtr sc, const LightF& lf, uint64_t pr
 }
 
 #ifndef CRT_WF_FILTER_WAVES
-#define CRT_WF_FILTER_WAVES 8
+#define CRT_WF_FILTER_WAVES 4
 #endif
 __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end) {
     ScenePtr sc = (ScenePtr)w.r.scene;
@@ -694,7 +943,7 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
     Stage st = {0u, 0u, 0u};
     uint32_t tally = 0;
     const size_t cw = w.cap_work;
-    const uint32_t n_geom = sc->n_geom, n_lights = sc->n_lights;
+    const uint32_t n_lights = sc->n_lights;
     for (uint32_t base = blockIdx.x * 64u; base < w_end - w_begin; base += gridDim.x * 64u) {
         const uint32_t wi = w_begin + base + lane;
         const uint32_t wr = wi < w_end ? wi : w_begin; // tail lanes shadow a valid index and discard the result
@@ -713,25 +962,19 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
             if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue; // no draws (Light.hpp:92-111, AreaLight.hpp:586)
             const uint32_t S = L->shadow_samples;
             const LightF lf = load_lightf(L);
-            const V3 Bp0 = lf.B0 - P, Bp1 = lf.B1 - P;
-            // primitives that may stop a shadow ray of some record of this wave
-            uint64_t prim_mask = 0;
-            for (uint32_t i = 0; i < n_geom; ++i) {
-                const DevGeomHot CRT_CONST* g = &sc->hot[i];
-                bool keep = true;
-                if (g->kind != CRT_GEOM_SPHERE) {
-                    const V3 q = P - ld3c(g->o);
-                    const float s = (q.x * g->n[0] + q.y * g->n[1]) + q.z * g->n[2];
-                    keep = !(s * sc->cull_side[li][i] > sc->cull_thr[li][i]);
-                }
-                if (__any(keep)) prim_mask |= 1ull << i;
-            }
+            const RecordFilter rf = make_record_filter(sc, li, lf, P);
             uint32_t shadowed = 0;
             const uint32_t key = wi | (li << 28);
             uint32_t s = 0;
-            for (; s + 5u <= S; s += 5u)
-                filter_block<5>(w, sc, lf, prim_mask, act, P, Bp0, Bp1, rng, key, shadowed, stg, st, lane, tally);
-            for (; s < S; ++s) filter_block<1>(w, sc, lf, prim_mask, act, P, Bp0, Bp1, rng, key, shadowed, stg, st, lane, tally);
+            if (rf.poly && rf.rest_mask == 0) { // every candidate has a slot: the sample loop is polynomial evaluation only
+                for (; s + 5u <= S; s += 5u)
+                    filter_block<5, true>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
+                for (; s < S; ++s) filter_block<1, true>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
+            } else {
+                for (; s + 5u <= S; s += 5u)
+                    filter_block<5, false>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
+                for (; s < S; ++s) filter_block<1, false>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
+            }
             if (act) w.shadow_cnt[(size_t)li * cw + wi] = shadowed;
         }
     }
@@ -748,7 +991,7 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
     ScenePtr sc = (ScenePtr)w.r.scene;
     const uint32_t lane = threadIdx.x;
     const size_t cw = w.cap_work;
-    const uint32_t n_geom = sc->n_geom, n_lights = sc->n_lights;
+    const uint32_t n_lights = sc->n_lights;
     unsigned long long decided = 0, bad = 0;
     for (uint32_t base = blockIdx.x * 64u; base < w_end - w_begin; base += gridDim.x * 64u) {
         const uint32_t wi = w_begin + base + lane;
@@ -769,40 +1012,11 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
             const uint32_t S = L->shadow_samples;
             const LightF lf = load_lightf(L);
             const LightC lc = load_lightc(L);
-            const V3 Bp0 = lf.B0 - P, Bp1 = lf.B1 - P;
-            uint64_t prim_mask = 0;
-            for (uint32_t i = 0; i < n_geom; ++i) {
-                const DevGeomHot CRT_CONST* g = &sc->hot[i];
-                bool keep = true;
-                if (g->kind != CRT_GEOM_SPHERE) {
-                    const V3 q = P - ld3c(g->o);
-                    const float s = (q.x * g->n[0] + q.y * g->n[1]) + q.z * g->n[2];
-                    keep = !(s * sc->cull_side[li][i] > sc->cull_thr[li][i]);
-                }
-                if (keep) prim_mask |= 1ull << i;
-            }
-            // per lane: the primitives this record did not cull (the filter uses the union over the wave,
-            // which can only add tests)
+            const RecordFilter rf = make_record_filter(sc, li, lf, P);
             for (uint32_t s = 0; s < S; ++s) {
                 const float u = rng_uniform(rng), v = rng_uniform(rng);
-                V3 D[1];
-                float a[1];
-                D[0] = sample_offset(lf, Bp0, Bp1, u, v);
-                a[0] = __builtin_fmaf(D[0].x, D[0].x, __builtin_fmaf(D[0].y, D[0].y, D[0].z * D[0].z));
-                Classes k = {0u, 0u, 0u};
-                // classify_block wants a wave-uniform mask: walk the union, apply this lane's bit
-                uint64_t un = 0;
-                for (uint32_t i = 0; i < n_geom; ++i)
-                    if (__any((prim_mask >> i) & 1ull)) un |= 1ull << i;
-                for (uint64_t m = un; m != 0; m &= m - 1u) {
-                    const uint32_t i = (uint32_t)__builtin_ctzll(m);
-                    const Classes one = classify_block<1>(sc, 1ull << i, P, D, a);
-                    if ((prim_mask >> i) & 1ull) {
-                        k.sure_opaque |= one.sure_opaque;
-                        k.maybe_any |= one.maybe_any;
-                        k.maybe_glass |= one.maybe_glass;
-                    }
-                }
+                const float us[1] = {u}, vs[1] = {v};
+                const Classes k = classify_samples<1, false>(sc, lf, rf, us, vs);
                 const bool covered = k.sure_opaque && !k.maybe_glass;
                 const bool unresolved = !covered && (k.maybe_any || k.sure_opaque);
                 if (act && !unresolved) {
