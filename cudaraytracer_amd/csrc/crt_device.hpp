@@ -454,6 +454,48 @@ DI Hit closest_hit(ScenePtr sc, V3 o, V3 d, float dist) {
     return h;
 }
 
+// closest_hit restricted to the primitives in `mask` (per lane); primitives outside it are known not to be
+// hit by this ray, so the result is that of closest_hit.
+DI Hit closest_hit_masked(ScenePtr sc, V3 o, V3 d, float dist, uint64_t mask) {
+    Hit h;
+    h.idx = -1;
+    h.mat_type = 0;
+    h.t = kFltMax;
+    h.u = 0.0f;
+    h.v = 0.0f;
+    const float dd = dot3(d, d);
+    const uint32_t n = sc->n_geom;
+    for (uint32_t i = 0; i < n; ++i) {
+        const bool mine = (mask >> i) & 1ull;
+        if (!__any(mine)) continue;
+        const DevGeomHot CRT_CONST* g = &sc->hot[i];
+        const uint32_t kind = g->kind, mat = g->mat_type;
+        const V3 go = ld3c(g->o), gn = ld3c(g->n);
+        float t = 0.0f, u = 0.0f, v = 0.0f;
+        bool hit = false;
+        if (mine) {
+            if (kind == CRT_GEOM_SPHERE) {
+                hit = sphere_t(go, gn.x, o, d, dd, dist, t);
+            } else {
+                V3 p = o - go;
+                hit = quad_plane_t(p, d, gn, dist, h.t, t);
+                if (hit) {
+                    UVRec q = load_uv(&sc->uv[i]);
+                    hit = quad_uv<false>(q, p, d, t, u, v);
+                }
+            }
+        }
+        if (hit && !(t > h.t)) {
+            h.idx = (int)i;
+            h.mat_type = mat;
+            h.t = t;
+            h.u = u;
+            h.v = v;
+        }
+    }
+    return h;
+}
+
 // Hit point and shading normal of an accepted hit (Sphere.hpp:102-107, Quad.hpp:299-325).
 DI void hit_point_normal(ScenePtr sc, const Hit& h, V3 o, V3 d, V3& P, V3& N) {
     P = o + d * h.t;

@@ -39,6 +39,7 @@ namespace {
 enum : uint32_t { TAG_ADD = 0, TAG_END_CALL = 1, TAG_END_PIXEL = 2 };
 constexpr uint32_t kWorkChunk = 256;         // shade-record indices a trace wave reserves at a time
 constexpr uint32_t kMaxFilterWaves = 16384;   // upper bound of the filter kernel's grid
+constexpr uint32_t kResolveSplit = 8;         // resolve waves per filter wave's queue region
 constexpr uint32_t kNoRecord = 0xffffffffu;  // primitive index of an unused record slot
 
 // state planes
@@ -774,13 +775,10 @@ struct RecordFilter {
     QuadSlot q;
 };
 
-DI RecordFilter make_record_filter(ScenePtr sc, uint32_t li, const LightF& lf, V3 P) {
-    RecordFilter f;
-    f.P = P;
-    f.Bp0 = lf.B0 - P;
-    f.Bp1 = lf.B1 - P;
-    // primitives that may stop a shadow ray of some record of this wave
-    uint64_t prim_mask = 0;
+// Primitives that may stop a shadow ray from P towards light `li` (per lane): all spheres, and the quads
+// the per-light plane test of DevScene::cull_side / cull_thr does not exclude.
+DI uint64_t shadow_candidates(ScenePtr sc, uint32_t li, V3 P) {
+    uint64_t mask = 0;
     const uint32_t n_geom = sc->n_geom;
     for (uint32_t i = 0; i < n_geom; ++i) {
         const DevGeomHot CRT_CONST* g = &sc->hot[i];
@@ -790,8 +788,22 @@ DI RecordFilter make_record_filter(ScenePtr sc, uint32_t li, const LightF& lf, V
             const float s = (q.x * g->n[0] + q.y * g->n[1]) + q.z * g->n[2];
             keep = !(s * sc->cull_side[li][i] > sc->cull_thr[li][i]);
         }
-        if (__any(keep)) prim_mask |= 1ull << i;
+        if (keep) mask |= 1ull << i;
     }
+    return mask;
+}
+
+DI RecordFilter make_record_filter(ScenePtr sc, uint32_t li, const LightF& lf, V3 P) {
+    RecordFilter f;
+    f.P = P;
+    f.Bp0 = lf.B0 - P;
+    f.Bp1 = lf.B1 - P;
+    // primitives that may stop a shadow ray of some record of this wave
+    const uint64_t lane_mask = shadow_candidates(sc, li, P);
+    uint64_t prim_mask = 0;
+    const uint32_t n_geom = sc->n_geom;
+    for (uint32_t i = 0; i < n_geom; ++i)
+        if (__any((lane_mask >> i) & 1ull)) prim_mask |= 1ull << i;
     f.poly = lf.is_par;
     f.sph_i[0] = f.sph_i[1] = f.quad_i = -1;
     f.sph_glass[0] = f.sph_glass[1] = f.quad_glass = false;
@@ -1043,15 +1055,53 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
 }
 
 // -------------------------------------------------------------------------------------- resolve
+constexpr uint32_t kGlassCap = 128; // < 64 left over + 64 new entries per group of rays
+
+// Runs the refraction walk of Light::_isCovered (Light.hpp:47-80) on up to 64 queued glass hits.
+DI void glass_batch(const WfArgs& w, ScenePtr sc, float (*gq_f)[kGlassCap], uint32_t (*gq_u)[kGlassCap], uint32_t& gq,
+                    uint32_t lane) {
+    const uint32_t n = gq < 64u ? gq : 64u;
+    const uint32_t base = gq - n;
+    __syncthreads();
+    const bool act = lane < n;
+    const uint32_t slot = base + (act ? lane : 0u);
+    const V3 o = mk3(gq_f[0][slot], gq_f[1][slot], gq_f[2][slot]);
+    const V3 d = mk3(gq_f[3][slot], gq_f[4][slot], gq_f[5][slot]);
+    Hit h;
+    h.mat_type = CRT_MAT_REFRACTIVE;
+    h.t = gq_f[6][slot];
+    h.u = gq_f[7][slot];
+    h.v = gq_f[8][slot];
+    const uint32_t key = gq_u[0][slot];
+    h.idx = (int)gq_u[1][slot];
+    const uint32_t my_light = key >> 28;
+    const uint32_t n_lights = sc->n_lights;
+    for (uint32_t li = 0; li < n_lights; ++li) {
+        const bool mine = act && my_light == li;
+        if (!__any(mine)) continue;
+        const DevLight CRT_CONST* L = &sc->lights[li];
+        if (mine && covered_through_glass(sc, L, o, d, h))
+            atomicAdd(&w.shadow_cnt[(size_t)li * w.cap_work + (key & 0x0fffffffu)], 1u);
+    }
+    gq = base;
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
     ScenePtr sc = (ScenePtr)w.r.scene;
     const uint32_t lane = threadIdx.x;
     const size_t cw = w.cap_work;
     const uint32_t n_lights = sc->n_lights;
-    const uint32_t qcount = min(w.qcounts[blockIdx.x], w.region_cap);
-    const size_t region = (size_t)blockIdx.x * w.region_cap;
+    // rays whose closest hit is glass wait here until 64 of them can walk together
+    __shared__ float gq_f[9][kGlassCap];    // origin, direction, first hit (t, u, v)
+    __shared__ uint32_t gq_u[2][kGlassCap]; // queue key (record | light << 28), primitive
+    uint32_t gq = 0;                        // wave-uniform fill
+    // kResolveSplit waves share one filter wave's region, taking every kResolveSplit-th group of 64 rays
+    const uint32_t reg = blockIdx.x / kResolveSplit, part = blockIdx.x % kResolveSplit;
+    const uint32_t qcount = min(w.qcounts[reg], w.region_cap);
+    const size_t region = (size_t)reg * w.region_cap;
     uint32_t glass_tally = 0;
-    for (uint32_t base = 0; base < qcount; base += 64u) {
+    for (uint32_t base = part * 64u; base < qcount; base += kResolveSplit * 64u) {
         const bool act = base + lane < qcount;
         const size_t idx = region + base + lane;
         uint32_t key = 0;
@@ -1065,32 +1115,50 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
             P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
         }
         const uint32_t my_light = key >> 28;
+        bool glass = false;
+        V3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
+        Hit h;
+        h.idx = -1;
+        h.mat_type = 0;
+        h.t = h.u = h.v = 0.0f;
         for (uint32_t li = 0; li < n_lights; ++li) {
             const bool mine = act && my_light == li;
             if (!__any(mine)) continue;
             const DevLight CRT_CONST* L = &sc->lights[li];
             const LightC lc = load_lightc(L);
             if (mine) {
-                V3 o, d;
                 float x;
                 shadow_ray(lc, P, u, v, o, d, x);
-                // Light::_isCovered (Light.hpp:35-86)
-                Hit h = closest_hit(sc, o, d, x);
-                bool covered = false;
+                // first pass of Light::_isCovered (Light.hpp:35-46)
+                h = closest_hit_masked(sc, o, d, x, shadow_candidates(sc, li, P));
                 if (h.idx >= 0) {
-                    if (h.mat_type != CRT_MAT_REFRACTIVE) {
-                        covered = true;
-                    } else {
-                        ++glass_tally;
-                        covered = covered_through_glass(sc, L, o, d, h);
-                    }
+                    if (h.mat_type != CRT_MAT_REFRACTIVE) atomicAdd(&w.shadow_cnt[(size_t)li * cw + (key & 0x0fffffffu)], 1u);
+                    else glass = true;
                 }
-                if (covered) atomicAdd(&w.shadow_cnt[(size_t)li * cw + (key & 0x0fffffffu)], 1u);
             }
         }
+        const uint64_t gm = __ballot(glass);
+        if (gm != 0) {
+            if (glass) {
+                const uint32_t slot = gq + lane_rank(gm);
+                gq_f[0][slot] = o.x;
+                gq_f[1][slot] = o.y;
+                gq_f[2][slot] = o.z;
+                gq_f[3][slot] = d.x;
+                gq_f[4][slot] = d.y;
+                gq_f[5][slot] = d.z;
+                gq_f[6][slot] = h.t;
+                gq_f[7][slot] = h.u;
+                gq_f[8][slot] = h.v;
+                gq_u[0][slot] = key;
+                gq_u[1][slot] = (uint32_t)h.idx;
+            }
+            gq += (uint32_t)__popcll(gm);
+            glass_tally += (uint32_t)__popcll(gm);
+            if (gq >= 64u) glass_batch(w, sc, gq_f, gq_u, gq, lane);
+        }
     }
-    // wave sum of the glass tally
-    for (int off = 32; off > 0; off >>= 1) glass_tally += __shfl_down(glass_tally, off, 64);
+    while (gq != 0u) glass_batch(w, sc, gq_f, gq_u, gq, lane);
     if (lane == 0 && glass_tally != 0u) atomicAdd(&w.r.wave_tallies[1], (unsigned long long)glass_tally);
 }
 
@@ -1328,7 +1396,7 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
             const uint32_t fgrid = groups < fwaves ? groups : fwaves;
             hipLaunchKernelGGL(wf_filter_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
             if (args.audit) hipLaunchKernelGGL(wf_audit_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
-            hipLaunchKernelGGL(wf_resolve_kernel, dim3(fgrid), dim3(64), 0, stream, w);
+            hipLaunchKernelGGL(wf_resolve_kernel, dim3(fgrid * kResolveSplit), dim3(64), 0, stream, w);
         }
         if (n_work != 0u)
             hipLaunchKernelGGL(wf_shade_kernel, dim3((n_work + 63u) / 64u), dim3(64), 0, stream, w, n_work);
