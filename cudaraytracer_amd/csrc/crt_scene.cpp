@@ -249,6 +249,11 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
         }
         b.n2 = 0.0f;
         b.sp_min2 = INFINITY;
+        for (int k = 0; k < 3; ++k) {
+            b.lo_in[k] = INFINITY;
+            b.hi_in[k] = -INFINITY;
+        }
+        b.pad[0] = b.pad[1] = 0.0f;
         if (i < in->n_geometry && in->geometry[i].kind == CRT_GEOM_QUAD && rabs > 0.0 && rabs < 1e6) {
             const DevGeomHot& hq = out->hot[i];
             const double n2 = (double)hq.n[0] * hq.n[0] + (double)hq.n[1] * hq.n[1] + (double)hq.n[2] * hq.n[2];
@@ -274,6 +279,49 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
             b.lo[k] = (float)(lo - margin);
             b.hi[k] = (float)(hi + margin);
         }
+        // axis-aligned rectangle: every vertex sits on a corner of the kept-axes box, all four corners used
+        {
+            const uint32_t ku = keep[0], kv = keep[1];
+            double lo2[2] = {INFINITY, INFINITY}, hi2[2] = {-INFINITY, -INFINITY};
+            for (int v = 0; v < 4; ++v) {
+                lo2[0] = fmin(lo2[0], (double)in->geometry[i].v[v].pos[ku]);
+                hi2[0] = fmax(hi2[0], (double)in->geometry[i].v[v].pos[ku]);
+                lo2[1] = fmin(lo2[1], (double)in->geometry[i].v[v].pos[kv]);
+                hi2[1] = fmax(hi2[1], (double)in->geometry[i].v[v].pos[kv]);
+            }
+            const double tol = 1e-6 * rabs;
+            unsigned corners = 0;
+            bool on_corner = true;
+            for (int v = 0; v < 4; ++v) {
+                const double pu = in->geometry[i].v[v].pos[ku], pv = in->geometry[i].v[v].pos[kv];
+                const bool ulo = fabs(pu - lo2[0]) <= tol, uhi = fabs(pu - hi2[0]) <= tol;
+                const bool vlo = fabs(pv - lo2[1]) <= tol, vhi = fabs(pv - hi2[1]) <= tol;
+                if (!(ulo || uhi) || !(vlo || vhi)) on_corner = false;
+                corners |= 1u << ((uhi ? 1 : 0) | (vhi ? 2 : 0));
+            }
+            const bool wide = hi2[0] - lo2[0] > 4.0 * margin && hi2[1] - lo2[1] > 4.0 * margin;
+            if (on_corner && corners == 15u && wide) {
+                for (int k = 0; k < 3; ++k) {
+                    b.lo_in[k] = -INFINITY;
+                    b.hi_in[k] = INFINITY;
+                }
+                b.lo_in[ku] = (float)(lo2[0] + margin);
+                b.hi_in[ku] = (float)(hi2[0] - margin);
+                b.lo_in[kv] = (float)(lo2[1] + margin);
+                b.hi_in[kv] = (float)(hi2[1] - margin);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < CRT_MAX_GEOMETRY; ++i) {
+        DevGeomBox& b = out->box[i];
+        for (int k = 0; k < 3; ++k) {
+            const bool bounded = b.lo[k] > -INFINITY && b.hi[k] < INFINITY;
+            b.mid[k] = bounded ? 0.5f * (b.lo[k] + b.hi[k]) : 0.0f;
+            b.half_out[k] = bounded ? 0.5f * (b.hi[k] - b.lo[k]) : INFINITY;
+            const bool inner = b.lo_in[0] < INFINITY; // rectangle with an inner box
+            b.half_in[k] = !inner ? -1.0f : (bounded ? 0.5f * (b.hi_in[k] - b.lo_in[k]) : INFINITY);
+        }
+        for (int k = 0; k < 7; ++k) b.pad2[k] = 0.0f;
     }
     const double dmax = 3.5 * rabs; // > 2*sqrt(3)*rabs: no two scene points are further apart
     for (uint32_t l = 0; l < CRT_MAX_LIGHTS; ++l)
@@ -286,6 +334,19 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
         for (uint32_t i = 0; i < in->n_geometry; ++i) {
             const DevGeomHot& h = out->hot[i];
             if (h.kind == CRT_GEOM_SPHERE) continue;
+            {
+                const DevLight& dl = out->lights[l];
+                double d1 = 0, d2 = 0, nn = 0, e1 = 0, e3 = 0;
+                for (int k = 0; k < 3; ++k) {
+                    d1 += (double)h.n[k] * dl.e01[k];
+                    d2 += (double)h.n[k] * dl.e03[k];
+                    nn += (double)h.n[k] * h.n[k];
+                    e1 += (double)dl.e01[k] * dl.e01[k];
+                    e3 += (double)dl.e03[k] * dl.e03[k];
+                }
+                const bool par = dl.is_par && fabs(d1) <= 1e-6 * sqrt(nn * e1) && fabs(d2) <= 1e-6 * sqrt(nn * e3);
+                out->quad_par[l][i] = par ? 1u : 0u;
+            }
             const double nlen = sqrt((double)h.n[0] * h.n[0] + (double)h.n[1] * h.n[1] + (double)h.n[2] * h.n[2]);
             if (!(nlen > 1e-12) || !(nlen < 1e12) || !(rabs > 0.0) || !(rabs < 1e6)) continue;
             double smin = INFINITY, smax = -INFINITY;

@@ -46,10 +46,18 @@ struct alignas(16) DevGeomUV { // quad only (Quad.hpp:232-250): everything that 
 // [lo, hi] (already widened by 1e-3 of the scene size) on an axis the reference keeps for its (u,v)
 // solve (Quad.hpp:232-250) cannot yield 0 <= u,v <= 1.  The dropped axis and every axis of a sphere or
 // of a non-parallelogram quad carry -inf/+inf, which never reject.
-struct alignas(32) DevGeomBox {
+struct alignas(64) DevGeomBox {
     float lo[3], hi[3];
     float n2;      // |nor|^2
     float sp_min2; // (1e-4 * |nor| * scene size)^2: a point this far off the plane is robustly off it
+    // For an axis-aligned rectangle the same box shrunk by the margin lies inside the quad: a plane
+    // hit inside [lo_in, hi_in] on the kept axes certainly has 0 < u,v < 1.  lo_in = +inf otherwise.
+    float lo_in[3], hi_in[3];
+    float pad[2];
+    // The same boxes as centre and half-widths: |x - mid| > half_out rejects, |x - mid| < half_in is
+    // inside the rectangle.  Unused axes: mid 0, half-widths +inf; no inner box: half_in -1.
+    float mid[3], half_out[3], half_in[3];
+    float pad2[7];
 };
 
 struct alignas(16) DevGeomShade {
@@ -111,6 +119,8 @@ struct alignas(64) DevScene {
     // s * cull_side[l][g] > cull_thr[l][g] (the whole light lies on that side of the quad's plane,
     // further than the 0.01 the ray overshoots, and P is on the same side or on the plane itself).
     // cull_thr = +inf where no such statement holds (spheres, quads the light straddles or touches).
+    // 1 when quad g is parallel to the plane of area light l (nor.D is then the same for every sample)
+    uint32_t quad_par[CRT_MAX_LIGHTS][CRT_MAX_GEOMETRY];
     float cull_side[CRT_MAX_LIGHTS][CRT_MAX_GEOMETRY];
     float cull_thr[CRT_MAX_LIGHTS][CRT_MAX_GEOMETRY];
 };

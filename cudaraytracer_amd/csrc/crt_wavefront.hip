@@ -682,6 +682,14 @@ struct QuadSlot {
 struct PolyA {
     float h0, h1x2, h2x2;
 };
+// Quad parallel to the light: dnq = nor.D is one number per shaded point, so the plane is met at the
+// fixed ray parameter s_c = -sP/dnq and the plane point P + s_c D is affine in (u, v); the statements
+// of quad_slot_class that involve a = D.D turn into thresholds on a.
+struct QuadParSlot {
+    float r[3][3];        // [axis][1, u, v]: plane point minus the box centre
+    float t_lift, t_beyond, t_steep, t_between; // free if a < t_lift or a > t_beyond; box tests need a < t_steep; sure needs a > t_between
+    bool behind;
+};
 
 DI SphSlot make_sph_slot(V3 P, V3 center, float r2, V3 Bp, const LightF& lf, const PolyA& pa, float a_max) {
     SphSlot s;
@@ -736,26 +744,73 @@ DI QuadSlot make_quad_slot(V3 P, V3 v0, V3 nor, float sp_min2, V3 Bp, const Ligh
     }
     return q;
 }
-// true: free for sure (same statements as the quad part of classify_block)
-DI bool quad_slot_free(const QuadSlot& q, V3 blo, V3 bhi, float n2, const PolyA& pa, const LightF& lf, float u, float v) {
+// 0 free, 1 undecided, 2 sure.  "Free" repeats the quad statements of classify_block.  "Sure" (axis-aligned
+// rectangles only): the plane lies between P and the sample (s_c = |sP|/|dnq| < 0.999), more than 0.011 of
+// ray length away from P (so t = s_c |D| - 0.01 > 0), the ray is not grazing, and the plane point is
+// inside the rectangle shrunk by the margin, where the reference's 0 <= u,v <= 1 certainly holds.
+DI uint32_t quad_slot_class(const QuadSlot& q, V3 blo, V3 bhi, V3 ilo, V3 ihi, float n2, const PolyA& pa, const LightF& lf,
+                            float u, float v) {
     const float dnq = __builtin_fmaf(q.d2, v, __builtin_fmaf(q.d1, u, q.d0));
     const float a = __builtin_fmaf(__builtin_fmaf(lf.g11, u, __builtin_fmaf(lf.g12x2, v, pa.h1x2)), u,
                                    __builtin_fmaf(__builtin_fmaf(lf.g22, v, pa.h2x2), v, pa.h0));
     const float dn2 = dnq * dnq, sP2 = q.sP * q.sP;
-    const bool same = q.sP * dnq > 0.0f;
+    const float sd = q.sP * dnq;
+    const bool same = sd > 0.0f;
     const bool behind = same && q.offp;
     const bool lifted = sP2 * a < 2.5e-5f * dn2 && dn2 > 4e-6f * (n2 * a);
-    const float e = __builtin_fabsf(q.sP) - __builtin_fabsf(dnq) * 1.000004f;
-    const bool beyond = !same && q.offp && e > 0.0f && (e * e) * a > 1.004004e-4f * dn2;
     const float ad = __builtin_fabsf(dnq);
+    const float e = __builtin_fabsf(q.sP) - ad * 1.000004f;
+    const bool beyond = !same && q.offp && e > 0.0f && (e * e) * a > 1.004004e-4f * dn2;
     const float sg = dnq < 0.0f ? -1.0f : 1.0f;
     const float qx = __builtin_fmaf(q.q[0][2], v, __builtin_fmaf(q.q[0][1], u, q.q[0][0])) * sg;
     const float qy = __builtin_fmaf(q.q[1][2], v, __builtin_fmaf(q.q[1][1], u, q.q[1][0])) * sg;
     const float qz = __builtin_fmaf(q.q[2][2], v, __builtin_fmaf(q.q[2][1], u, q.q[2][0])) * sg;
     const bool outside = qx < blo.x * ad || qx > bhi.x * ad || qy < blo.y * ad || qy > bhi.y * ad || qz < blo.z * ad ||
                          qz > bhi.z * ad;
-    const bool boxed_out = outside && dn2 > 1e-4f * (n2 * a);
-    return behind || lifted || beyond || boxed_out;
+    const bool steep = dn2 > 1e-4f * (n2 * a);
+    if (behind || lifted || beyond || (outside && steep)) return 0u;
+    const bool inside = qx > ilo.x * ad && qx < ihi.x * ad && qy > ilo.y * ad && qy < ihi.y * ad && qz > ilo.z * ad &&
+                        qz < ihi.z * ad;
+    const bool between = sd < 0.0f && q.offp && steep && __builtin_fabsf(q.sP) < 0.999f * ad && sP2 * a > 1.21e-4f * dn2;
+    return (inside && between) ? 2u : 1u;
+}
+
+DI QuadParSlot make_quad_par_slot(V3 P, V3 v0, V3 nor, float sp_min2, float n2, V3 mid, V3 Bp, const LightF& lf) {
+    QuadParSlot q;
+    const V3 pq = P - v0;
+    const float sP = fdot(pq, nor), dnq = fdot(nor, Bp);
+    const float sP2 = sP * sP, dn2 = dnq * dnq, ad = __builtin_fabsf(dnq);
+    const bool offp = sP2 > sp_min2;
+    const float sd = sP * dnq;
+    q.behind = sd > 0.0f && offp;
+    const float inf = __builtin_inff();
+    q.t_lift = __builtin_fminf(2.5e-5f * dn2 / sP2, dn2 / (4e-6f * n2));
+    const float e = __builtin_fabsf(sP) - ad * 1.000004f;
+    q.t_beyond = (!(sd > 0.0f) && offp && e > 0.0f) ? 1.004004e-4f * dn2 / (e * e) * 1.00001f : inf;
+    q.t_steep = dn2 / (1e-4f * n2) * 0.99999f;
+    q.t_between = (sd < 0.0f && offp && __builtin_fabsf(sP) < 0.999f * ad) ? 1.21e-4f * dn2 / sP2 * 1.00001f : inf;
+    const float sc_ = -sP / dnq; // ray parameter of the plane
+    const float Pk[3] = {P.x, P.y, P.z}, Bk[3] = {Bp.x, Bp.y, Bp.z}, e1[3] = {lf.e01.x, lf.e01.y, lf.e01.z},
+                e3[3] = {lf.e03.x, lf.e03.y, lf.e03.z}, mk[3] = {mid.x, mid.y, mid.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        q.r[k][0] = __builtin_fmaf(sc_, Bk[k], Pk[k] - mk[k]);
+        q.r[k][1] = sc_ * e1[k];
+        q.r[k][2] = sc_ * e3[k];
+    }
+    return q;
+}
+DI uint32_t quad_par_slot_class(const QuadParSlot& q, V3 hout, V3 hin, const PolyA& pa, const LightF& lf, float u, float v) {
+    const float a = __builtin_fmaf(__builtin_fmaf(lf.g11, u, __builtin_fmaf(lf.g12x2, v, pa.h1x2)), u,
+                                   __builtin_fmaf(__builtin_fmaf(lf.g22, v, pa.h2x2), v, pa.h0));
+    const float rx = __builtin_fabsf(__builtin_fmaf(q.r[0][2], v, __builtin_fmaf(q.r[0][1], u, q.r[0][0])));
+    const float ry = __builtin_fabsf(__builtin_fmaf(q.r[1][2], v, __builtin_fmaf(q.r[1][1], u, q.r[1][0])));
+    const float rz = __builtin_fabsf(__builtin_fmaf(q.r[2][2], v, __builtin_fmaf(q.r[2][1], u, q.r[2][0])));
+    const bool steep = a < q.t_steep;
+    const bool outside = rx > hout.x || ry > hout.y || rz > hout.z;
+    if (q.behind || a < q.t_lift || a > q.t_beyond || (outside && steep)) return 0u;
+    const bool inside = rx < hin.x && ry < hin.y && rz < hin.z;
+    return (inside && steep && a > q.t_between) ? 2u : 1u;
 }
 
 // Everything the filter derives once per (shaded point, light) before its sample loop.
@@ -763,8 +818,8 @@ struct RecordFilter {
     // wave-uniform
     bool poly;
     int sph_i[2], quad_i;
-    bool sph_glass[2], quad_glass;
-    V3 blo, bhi;
+    bool sph_glass[2], quad_glass, quad_par;
+    V3 blo, bhi, ilo, ihi;
     float n2;
     uint64_t rest_mask;
     // per lane
@@ -773,6 +828,8 @@ struct RecordFilter {
     PolyA pa;
     SphSlot s[2];
     QuadSlot q;
+    QuadParSlot qp;
+    V3 hout, hin;
 };
 
 // Primitives that may stop a shadow ray from P towards light `li` (per lane): all spheres, and the quads
@@ -806,8 +863,9 @@ DI RecordFilter make_record_filter(ScenePtr sc, uint32_t li, const LightF& lf, V
         if (__any((lane_mask >> i) & 1ull)) prim_mask |= 1ull << i;
     f.poly = lf.is_par;
     f.sph_i[0] = f.sph_i[1] = f.quad_i = -1;
-    f.sph_glass[0] = f.sph_glass[1] = f.quad_glass = false;
-    f.blo = f.bhi = mk3(0, 0, 0);
+    f.sph_glass[0] = f.sph_glass[1] = f.quad_glass = f.quad_par = false;
+    f.hout = f.hin = mk3(0, 0, 0);
+    f.blo = f.bhi = f.ilo = f.ihi = mk3(0, 0, 0);
     f.n2 = 0.0f;
     f.rest_mask = prim_mask;
     f.rec_ok = true;
@@ -852,9 +910,18 @@ DI RecordFilter make_record_filter(ScenePtr sc, uint32_t li, const LightF& lf, V
     if (iq >= 0) {
         const DevGeomHot CRT_CONST* g = &sc->hot[iq];
         const DevGeomBox CRT_CONST* bx = &sc->box[iq];
-        f.q = make_quad_slot(P, ld3c(g->o), ld3c(g->n), bx->sp_min2, f.Bp0, lf);
+        f.quad_par = sc->quad_par[li][iq] != 0u;
+        if (f.quad_par) {
+            f.qp = make_quad_par_slot(P, ld3c(g->o), ld3c(g->n), bx->sp_min2, bx->n2, ld3c(bx->mid), f.Bp0, lf);
+            f.hout = ld3c(bx->half_out);
+            f.hin = ld3c(bx->half_in);
+        } else {
+            f.q = make_quad_slot(P, ld3c(g->o), ld3c(g->n), bx->sp_min2, f.Bp0, lf);
+        }
         f.blo = ld3c(bx->lo);
         f.bhi = ld3c(bx->hi);
+        f.ilo = ld3c(bx->lo_in);
+        f.ihi = ld3c(bx->hi_in);
         f.n2 = bx->n2;
         f.quad_i = iq;
         f.quad_glass = g->mat_type == CRT_MAT_REFRACTIVE;
@@ -899,9 +966,16 @@ DI Classes classify_samples(ScenePtr sc, const LightF& lf, const RecordFilter& f
         if (f.quad_i >= 0) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                if (!quad_slot_free(f.q, f.blo, f.bhi, f.n2, f.pa, lf, us[j], vs[j])) {
-                    k.maybe_any |= 1u << j;
-                    if (f.quad_glass) k.maybe_glass |= 1u << j;
+                const uint32_t c = f.quad_par ? quad_par_slot_class(f.qp, f.hout, f.hin, f.pa, lf, us[j], vs[j])
+                                              : quad_slot_class(f.q, f.blo, f.bhi, f.ilo, f.ihi, f.n2, f.pa, lf, us[j], vs[j]);
+                if (f.quad_glass) {
+                    if (c != 0u) {
+                        k.maybe_any |= 1u << j;
+                        k.maybe_glass |= 1u << j;
+                    }
+                } else {
+                    if (c == 1u) k.maybe_any |= 1u << j;
+                    if (c == 2u) k.sure_opaque |= 1u << j;
                 }
             }
         }
