@@ -72,384 +72,7 @@ struct WfArgs {
 DI float u2f(uint32_t x) { return __uint_as_float(x); }
 DI uint32_t f2u(float x) { return __float_as_uint(x); }
 
-// ---------------------------------------------------------------------------------------- trace
-__global__ void __launch_bounds__(64, 4) wf_trace_kernel(WfArgs w, uint32_t first) {
-    const RenderArgs& a = w.r;
-    ScenePtr sc = (ScenePtr)a.scene;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t unit = blockIdx.x;
-    const size_t n_lp = w.n_lp;
-    const size_t lp = (size_t)unit * 64u + lane;
-    const uint32_t npix = a.nx * a.ny;
-    const PixelMap pm = map_pixel(a, unit, lane);
-    const uint32_t pix = pm.valid ? pm.j * a.nx + pm.i : 0u;
-
-    // get_world_coordinates (main.cu:306-314) and pixel_size (main.cu:337)
-    const float height_world = 2.0f;
-    const float width_world = height_world * ((float)a.nx / (float)a.ny);
-    const float pix_w = width_world / (float)a.nx, pix_h = height_world / (float)a.ny;
-    // Camera::getRay constants (Camera.hpp:97-98,133-134)
-    const V3 cam_pos = ld3c(sc->cam.pos), cam_front = ld3c(sc->cam.front), cam_right = ld3c(sc->cam.right),
-             cam_up = ld3c(sc->cam.up);
-    const V3 eye = cam_pos - cam_front * (width_world * 0.5f * sc->cam.one_over_tan);
-    const uint32_t cam_type = sc->cam.type;
-    float ortho;
-    {
-        float aspect = height_world / width_world;
-        ortho = sc->cam.ortho_scale * (aspect > 1.0f ? aspect : 1.0f);
-    }
-    const uint32_t aa_iter = a.aa_iter;                // 0 or 1 here
-    const uint32_t n_calls = aa_iter == 0u ? 1u : 4u;  // color() calls per pixel (main.cu:254-268)
-    const float inv_ind = 1.0f / (float)a.ind_rays;    // main.cu:182
-    // generator draws one diffuse hit consumes in LightList::calculateColor (AreaLight.hpp:342-343,495)
-    uint32_t skip_draws = 0;
-    for (uint32_t li = 0; li < sc->n_lights; ++li) {
-        const DevLight CRT_CONST* L = &sc->lights[li];
-        if (L->kind == CRT_LIGHT_AREA && L->initialized) skip_draws += 2u * L->shadow_samples;
-    }
-
-    // ---- traversal state
-    uint32_t ctl = 0;
-    if (!first) ctl = w.state[ST_CTL * n_lp + lp];
-    bool done = !pm.valid || (ctl & 1u);
-    const bool live_at_entry = !done;
-    bool color_active = (ctl >> 1) & 1u, cur_valid = (ctl >> 2) & 1u;
-    uint32_t call = (ctl >> 4) & 15u, nframes = (ctl >> 8) & 15u;
-    Rng rng = {0, 0, 0, 0, 0, 0};
-    V3 cur_o = mk3(0, 0, 0), cur_d = mk3(0, 0, 0), ray_d = mk3(0.0f, 0.0f, -1.0f);
-    V4 cur_att = V4{1, 1, 1, 1};
-    uint32_t cur_ref = 0, cur_depth = 0, on_stack = 0;
-    if (live_at_entry) {
-        rng.v0 = a.rng[0 * (size_t)npix + pix];
-        rng.v1 = a.rng[1 * (size_t)npix + pix];
-        rng.v2 = a.rng[2 * (size_t)npix + pix];
-        rng.v3 = a.rng[3 * (size_t)npix + pix];
-        rng.v4 = a.rng[4 * (size_t)npix + pix];
-        rng.d = a.rng[5 * (size_t)npix + pix];
-        if (!first) {
-            const uint32_t* s = w.state + lp;
-            cur_o = mk3(u2f(s[(ST_CUR_O + 0) * n_lp]), u2f(s[(ST_CUR_O + 1) * n_lp]), u2f(s[(ST_CUR_O + 2) * n_lp]));
-            cur_d = mk3(u2f(s[(ST_CUR_D + 0) * n_lp]), u2f(s[(ST_CUR_D + 1) * n_lp]), u2f(s[(ST_CUR_D + 2) * n_lp]));
-            cur_att = V4{u2f(s[(ST_CUR_ATT + 0) * n_lp]), u2f(s[(ST_CUR_ATT + 1) * n_lp]),
-                         u2f(s[(ST_CUR_ATT + 2) * n_lp]), u2f(s[(ST_CUR_ATT + 3) * n_lp])};
-            cur_ref = s[ST_CUR_REF * n_lp];
-            cur_depth = s[ST_CUR_DEPTH * n_lp];
-            ray_d = mk3(u2f(s[(ST_RAY_D + 0) * n_lp]), u2f(s[(ST_RAY_D + 1) * n_lp]), u2f(s[(ST_RAY_D + 2) * n_lp]));
-            on_stack = s[ST_ON_STACK * n_lp];
-        }
-    }
-    // remap<float,true> (math_functions.hpp:31-45)
-    float x_world, y_world;
-    {
-        float denom = (float)a.nx - 0.0f;
-        float es = -width_world * 0.5f, ee = width_world * 0.5f;
-        x_world = (denom == 0.0f) ? (float)pm.i : es + ((ee - es) / denom) * ((float)pm.i - 0.0f);
-        float denomy = (float)a.ny - 0.0f;
-        y_world = (denomy == 0.0f) ? (float)pm.j : 1.0f + ((-1.0f - 1.0f) / denomy) * ((float)pm.j - 0.0f);
-    }
-
-    uint32_t cnt = 0; // result slots filled this round
-    uint32_t cnt_shade = 0, cnt_expand = 0;
-    const uint32_t quota = w.quota;
-    // Shade records are handed out to the wave in chunks of kWorkChunk consecutive indices, so the one
-    // global counter sees one atomic per chunk instead of one per step.
-    uint32_t chunk_base = 0, chunk_used = kWorkChunk; // wave-uniform
-    bool have_chunk = false;
-
-    for (;;) {
-        const bool go = !done && cnt < quota;
-        if (!__any(go)) break;
-        bool emit = false; // a diffuse hit to record
-        V3 n_P = mk3(0, 0, 0), n_N = mk3(0, 0, 0), n_view = mk3(0, 0, 0);
-        V4 n_att = V4{0, 0, 0, 0};
-        uint32_t n_geom = 0, n_depth = 0;
-        if (go) {
-            if (!cur_valid) {
-                if (!color_active) {
-                    if (call == n_calls) {
-                        // render() epilogue (main.cu:339-346) happens in the sum kernel
-                        w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_END_PIXEL;
-                        ++cnt;
-                        done = true;
-                    } else {
-                        // aa_color (main.cu:230-304): level-0 task = pixel centre, level-1 task = 4 corners
-                        float rx, ry;
-                        if (aa_iter == 0u) {
-                            rx = x_world;
-                            ry = y_world;
-                        } else {
-                            float hx = pix_w * 0.5f, hy = pix_h * 0.5f;
-                            float ox = (call & 1u) ? 1.0f : -1.0f, oy = (call & 2u) ? 1.0f : -1.0f;
-                            rx = x_world + ox * hx * 0.5f;
-                            ry = y_world + oy * hy * 0.5f;
-                        }
-                        // Camera::getRay (Camera.hpp:86-144)
-                        V3 ro, rd;
-                        if (cam_type == CRT_CAM_ORTHOGRAPHIC) {
-                            ro = ((cam_right * rx) * ortho + (cam_up * ry) * ortho) + cam_pos;
-                            rd = ray_dir(cam_front);
-                        } else {
-                            ro = (cam_right * rx + cam_up * ry) + cam_pos;
-                            rd = ray_dir(ro - eye);
-                        }
-                        cur_o = ro;
-                        cur_d = rd;
-                        cur_att = V4{1.0f, 1.0f, 1.0f, 1.0f};
-                        cur_ref = a.ref_iter;
-                        cur_depth = a.gl_iter;
-                        cur_valid = true;
-                        color_active = true;
-                        ray_d = mk3(0.0f, 0.0f, -1.0f);
-                        nframes = 0;
-                        on_stack = 0;
-                    }
-                } else if (nframes == 0) {
-                    // color() returned (main.cu:225): the sum kernel folds it into the pixel
-                    w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_END_CALL;
-                    ++cnt;
-                    color_active = false;
-                    ++call;
-                } else {
-                    // pop the next child of the innermost frame (children leave last-to-first)
-                    uint32_t* f = w.frames + ((size_t)(nframes - 1u) * WF_FRAME_PLANES) * n_lp + lp;
-                    Rng rv;
-                    rv.v0 = f[(FR_RNG + 0) * n_lp];
-                    rv.v1 = f[(FR_RNG + 1) * n_lp];
-                    rv.v2 = f[(FR_RNG + 2) * n_lp];
-                    rv.v3 = f[(FR_RNG + 3) * n_lp];
-                    rv.v4 = f[(FR_RNG + 4) * n_lp];
-                    rv.d = f[(FR_RNG + 5) * n_lp];
-                    float r2 = rng_current_uniform(rv);
-                    rng_unstep(rv);
-                    float r1 = rng_current_uniform(rv);
-                    rng_unstep(rv);
-                    V3 hp = mk3(u2f(f[(FR_P + 0) * n_lp]), u2f(f[(FR_P + 1) * n_lp]), u2f(f[(FR_P + 2) * n_lp]));
-                    V3 hn = mk3(u2f(f[(FR_N + 0) * n_lp]), u2f(f[(FR_N + 1) * n_lp]), u2f(f[(FR_N + 2) * n_lp]));
-                    V4 patt = V4{u2f(f[(FR_ATT + 0) * n_lp]), u2f(f[(FR_ATT + 1) * n_lp]), u2f(f[(FR_ATT + 2) * n_lp]),
-                                 u2f(f[(FR_ATT + 3) * n_lp])};
-                    const uint32_t fgeom = f[FR_GEOM * n_lp];
-                    V4 pdiff = ld4c(sc->shade[fgeom].diffuse);
-                    const uint32_t cdepth = f[FR_CHILD_DEPTH * n_lp];
-                    uint32_t rem = f[FR_REMAINING * n_lp] - 1u;
-                    if (rem == 0u) {
-                        --nframes;
-                    } else {
-                        f[FR_REMAINING * n_lp] = rem;
-                        f[(FR_RNG + 0) * n_lp] = rv.v0;
-                        f[(FR_RNG + 1) * n_lp] = rv.v1;
-                        f[(FR_RNG + 2) * n_lp] = rv.v2;
-                        f[(FR_RNG + 3) * n_lp] = rv.v3;
-                        f[(FR_RNG + 4) * n_lp] = rv.v4;
-                        f[(FR_RNG + 5) * n_lp] = rv.d;
-                    }
-                    --on_stack;
-                    // get_random_ray_values_in_hemisphere (main.cu:60-74)
-                    V3 Nx, Nz;
-                    surface_frame(hn, Nx, Nz);
-                    const float PI_2 = 6.28318530717958647692f;
-                    float sinTheta = 1.0f - r1 * r1;
-                    float phi = r2 * PI_2;
-                    float sp, cp;
-                    sincos_c(phi, sp, cp);
-                    float x = sinTheta * cp, z = sinTheta * sp;
-                    V3 wd = mk3(x * Nz.x + r1 * hn.x + z * Nx.x, x * Nz.y + r1 * hn.y + z * Nx.y,
-                                x * Nz.z + r1 * hn.z + z * Nx.z);
-                    cur_o = hp + wd * 0.01f;
-                    cur_d = wd;
-                    cur_att = ((pdiff * (2.0f * r1)) * patt) * inv_ind; // main.cu:186
-                    cur_ref = a.ref_iter;
-                    cur_depth = cdepth;
-                    cur_valid = true;
-                }
-            }
-            if (cur_valid) {
-                // ---- pop (main.cu:132-147)
-                cur_valid = false;
-                if (cur_ref != 0u) {
-                    if (!eps_equal(len_sq(cur_d), 0.0f, kEpsSq)) ray_d = normalize3(cur_d);
-                    const V3 ro = cur_o;
-                    Hit h = closest_hit(sc, ro, ray_d, 0.0f);
-                    if (h.idx < 0) {
-                        // final_color += attenuation * Color::black() (main.cu:149-151)
-                        const V4 c = cur_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
-                        w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_ADD;
-                        w.contrib[(size_t)cnt * n_lp + lp] = make_float4(c.x, c.y, c.z, c.w);
-                        ++cnt;
-                    } else {
-                        V3 P, N;
-                        hit_point_normal(sc, h, ro, ray_d, P, N);
-                        if (h.mat_type == CRT_MAT_DIFFUSE) {
-                            emit = true;
-                            n_P = P;
-                            n_N = N;
-                            n_view = neg(cur_d); // viewDir = -state.r_dir, the stored (un-normalised) direction
-                            n_att = cur_att;
-                            n_geom = (uint32_t)h.idx;
-                            n_depth = cur_depth;
-                        } else if (h.mat_type == CRT_MAT_REFLECT) {
-                            // get_reflect_ray (main.cu:76-81)
-                            V3 I = normalize3(ray_d);
-                            V3 rdir = reflect3(I, normalize3(N));
-                            cur_o = P + rdir * 0.01f;
-                            cur_d = rdir;
-                            cur_att = cur_att * ld4c(sc->shade[h.idx].diffuse);
-                            cur_ref = cur_ref - 1u;
-                            cur_valid = true;
-                        } else {
-                            // get_refraction_ray (main.cu:83-108)
-                            bool front_face = dot3(ray_d, N) < 0.0f;
-                            V3 norm = front_face ? N : neg(N);
-                            float ratio = sc->shade[h.idx].refract_index / 1.0f;
-                            if (front_face) ratio = rcp_exact(ratio);
-                            V3 rdn = normalize3(ray_d);
-                            float cos_theta = __builtin_fminf(dot3(neg(rdn), norm), 1.0f);
-                            float sin_theta = rcp_exact(rsqrt_c(1.0f - cos_theta * cos_theta));
-                            bool cannot_refract = ratio * sin_theta > 1.0f; // reflectance(...) > 1 never holds
-                            V3 dir = cannot_refract ? reflect3(rdn, norm) : refract3(rdn, norm, ratio);
-                            cur_o = P + dir * 0.01f;
-                            cur_d = dir;
-                            cur_att = cur_att * ld4c(sc->shade[h.idx].diffuse);
-                            cur_ref = cur_ref - 1u;
-                            cur_valid = true;
-                        }
-                    }
-                }
-            }
-        }
-        // ---- record the diffuse hits of this step (all lanes are here together)
-        const uint64_t em = __ballot(emit);
-        if (em != 0) {
-            const uint32_t n_emit = (uint32_t)__popcll(em);
-            const bool need_chunk = chunk_used + n_emit > kWorkChunk;
-            uint32_t new_base = 0;
-            if (need_chunk) {
-                if (lane == (uint32_t)__builtin_ctzll(em)) new_base = atomicAdd(&w.ctrs[WF_CTR_WORK], kWorkChunk);
-                new_base = (uint32_t)__builtin_amdgcn_readlane((int)new_base, __builtin_ctzll(em));
-            }
-            const uint32_t my_pos = chunk_used + lane_rank(em);
-            const uint32_t my_wi = my_pos < kWorkChunk ? chunk_base + my_pos : new_base + (my_pos - kWorkChunk);
-            if (need_chunk) {
-                chunk_base = new_base;
-                chunk_used = chunk_used + n_emit - kWorkChunk;
-                have_chunk = true;
-            } else {
-                chunk_used += n_emit;
-            }
-            if (emit) {
-                const uint32_t wi = my_wi;
-                const uint32_t slot_k = cnt;
-                w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_ADD;
-                ++cnt;
-                ++cnt_shade;
-                if (wi < w.cap_work) {
-                    uint32_t* r = w.work + wi;
-                    const size_t cw = w.cap_work;
-                    r[(WK_P + 0) * cw] = f2u(n_P.x);
-                    r[(WK_P + 1) * cw] = f2u(n_P.y);
-                    r[(WK_P + 2) * cw] = f2u(n_P.z);
-                    r[(WK_N + 0) * cw] = f2u(n_N.x);
-                    r[(WK_N + 1) * cw] = f2u(n_N.y);
-                    r[(WK_N + 2) * cw] = f2u(n_N.z);
-                    r[(WK_V + 0) * cw] = f2u(n_view.x);
-                    r[(WK_V + 1) * cw] = f2u(n_view.y);
-                    r[(WK_V + 2) * cw] = f2u(n_view.z);
-                    r[(WK_ATT + 0) * cw] = f2u(n_att.x);
-                    r[(WK_ATT + 1) * cw] = f2u(n_att.y);
-                    r[(WK_ATT + 2) * cw] = f2u(n_att.z);
-                    r[(WK_ATT + 3) * cw] = f2u(n_att.w);
-                    r[WK_GEOM * cw] = n_geom;
-                    r[(WK_RNG + 0) * cw] = rng.v0;
-                    r[(WK_RNG + 1) * cw] = rng.v1;
-                    r[(WK_RNG + 2) * cw] = rng.v2;
-                    r[(WK_RNG + 3) * cw] = rng.v3;
-                    r[(WK_RNG + 4) * cw] = rng.v4;
-                    r[(WK_RNG + 5) * cw] = rng.d;
-                    r[WK_SLOT * cw] = (uint32_t)((size_t)slot_k * n_lp + lp);
-                } else {
-                    w.ctrs[WF_CTR_ERROR] = 1u;
-                }
-                // the light samples of this hit (drawn by the filter kernel from the recorded state)
-                for (uint32_t k = 0; k < skip_draws; ++k) rng_step(rng);
-                if (n_depth > 0u) {
-                    ++cnt_expand;
-                    // The reference draws (r1,r2) for every child and pushes while its stack has room (main.cu:176-191).
-                    uint32_t room = on_stack < CRT_RAY_STACK ? CRT_RAY_STACK - on_stack : 0u;
-                    uint32_t accepted = a.ind_rays < room ? a.ind_rays : room;
-                    for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
-                    if (accepted > 0u) {
-                        uint32_t* f = w.frames + ((size_t)nframes * WF_FRAME_PLANES) * n_lp + lp;
-                        ++nframes;
-                        f[(FR_P + 0) * n_lp] = f2u(n_P.x);
-                        f[(FR_P + 1) * n_lp] = f2u(n_P.y);
-                        f[(FR_P + 2) * n_lp] = f2u(n_P.z);
-                        f[(FR_N + 0) * n_lp] = f2u(n_N.x);
-                        f[(FR_N + 1) * n_lp] = f2u(n_N.y);
-                        f[(FR_N + 2) * n_lp] = f2u(n_N.z);
-                        f[(FR_ATT + 0) * n_lp] = f2u(n_att.x);
-                        f[(FR_ATT + 1) * n_lp] = f2u(n_att.y);
-                        f[(FR_ATT + 2) * n_lp] = f2u(n_att.z);
-                        f[(FR_ATT + 3) * n_lp] = f2u(n_att.w);
-                        f[(FR_RNG + 0) * n_lp] = rng.v0;
-                        f[(FR_RNG + 1) * n_lp] = rng.v1;
-                        f[(FR_RNG + 2) * n_lp] = rng.v2;
-                        f[(FR_RNG + 3) * n_lp] = rng.v3;
-                        f[(FR_RNG + 4) * n_lp] = rng.v4;
-                        f[(FR_RNG + 5) * n_lp] = rng.d;
-                        f[FR_GEOM * n_lp] = n_geom;
-                        f[FR_REMAINING * n_lp] = accepted;
-                        f[FR_CHILD_DEPTH * n_lp] = n_depth - 1u;
-                        on_stack += accepted;
-                    }
-                    for (uint32_t k = 2u * accepted; k < 2u * a.ind_rays; ++k) rng_step(rng);
-                }
-            }
-        }
-    }
-
-    // ---- the unused tail of the last chunk holds no record
-    if (have_chunk)
-        for (uint32_t k = chunk_used + lane; k < kWorkChunk; k += 64u)
-            if (chunk_base + k < w.cap_work) w.work[(size_t)WK_GEOM * w.cap_work + chunk_base + k] = kNoRecord;
-
-    // ---- park the traversal
-    w.slot_count[lp] = cnt;
-    if (live_at_entry) {
-        a.rng[0 * (size_t)npix + pix] = rng.v0;
-        a.rng[1 * (size_t)npix + pix] = rng.v1;
-        a.rng[2 * (size_t)npix + pix] = rng.v2;
-        a.rng[3 * (size_t)npix + pix] = rng.v3;
-        a.rng[4 * (size_t)npix + pix] = rng.v4;
-        a.rng[5 * (size_t)npix + pix] = rng.d;
-        a.counters[pix] += cnt_shade;
-        a.counters[npix + pix] += cnt_expand;
-        uint32_t* s = w.state + lp;
-        s[ST_CTL * n_lp] = (done ? 1u : 0u) | (color_active ? 2u : 0u) | (cur_valid ? 4u : 0u) | (call << 4) | (nframes << 8);
-        if (!done) {
-            s[(ST_CUR_O + 0) * n_lp] = f2u(cur_o.x);
-            s[(ST_CUR_O + 1) * n_lp] = f2u(cur_o.y);
-            s[(ST_CUR_O + 2) * n_lp] = f2u(cur_o.z);
-            s[(ST_CUR_D + 0) * n_lp] = f2u(cur_d.x);
-            s[(ST_CUR_D + 1) * n_lp] = f2u(cur_d.y);
-            s[(ST_CUR_D + 2) * n_lp] = f2u(cur_d.z);
-            s[(ST_CUR_ATT + 0) * n_lp] = f2u(cur_att.x);
-            s[(ST_CUR_ATT + 1) * n_lp] = f2u(cur_att.y);
-            s[(ST_CUR_ATT + 2) * n_lp] = f2u(cur_att.z);
-            s[(ST_CUR_ATT + 3) * n_lp] = f2u(cur_att.w);
-            s[ST_CUR_REF * n_lp] = cur_ref;
-            s[ST_CUR_DEPTH * n_lp] = cur_depth;
-            s[(ST_RAY_D + 0) * n_lp] = f2u(ray_d.x);
-            s[(ST_RAY_D + 1) * n_lp] = f2u(ray_d.y);
-            s[(ST_RAY_D + 2) * n_lp] = f2u(ray_d.z);
-            s[ST_ON_STACK * n_lp] = on_stack;
-        }
-    } else if (first) {
-        w.state[ST_CTL * n_lp + lp] = 1u; // pixel slots outside the image never run
-    }
-    const uint64_t alive = __ballot(!done);
-    if (lane == 0 && alive != 0) atomicAdd(&w.ctrs[WF_CTR_ACTIVE], (uint32_t)__popcll(alive));
-}
-
-// --------------------------------------------------------------------------------------- filter
+// ------------------------------------------------------------------------- shadow-ray classification
 // Constants of AreaLight::_randomPoint (AreaLight.hpp:340-375) in scalar registers.
 struct LightC {
     V3 pos, p0, p2, e01, e03, e23, e21;
@@ -827,8 +450,10 @@ struct RecordFilter {
     V3 P, Bp0, Bp1;
     PolyA pa;
     SphSlot s[2];
-    QuadSlot q;
-    QuadParSlot qp;
+    union { // one of the two, by quad_par
+        QuadSlot q;
+        QuadParSlot qp;
+    };
     V3 hout, hin;
 };
 
@@ -1019,6 +644,502 @@ DI void filter_block(const WfArgs& w, ScenePtr sc, const LightF& lf, const Recor
     }
 }
 
+// Decision for all samples of one (shaded point, light) at once: 1 = every shadow ray is free,
+// 2 = every shadow ray is blocked by an opaque primitive, 0 = the samples have to be looked at one by
+// one.  Uses the slot polynomials: over the unit square of draws a polynomial c0 + cu s + cv t + A s^2 +
+// B st + C t^2 (s, t in [-1/2, 1/2] around the centre) lies within c0 +- (|cu| + |cv|)/2 +- the
+// quadratic terms' extremes, affine functions take their extremes at the four corners, and a = D.D is
+// convex.  Only parallelogram lights, spheres and quads parallel to the light are decided here.
+DI uint32_t record_light_class(ScenePtr sc, uint32_t li, const LightF& lf, V3 P) {
+    if (!lf.is_par) return 0u;
+    const V3 Bp = lf.B0 - P;
+    PolyA pa;
+    pa.h0 = fdot(Bp, Bp);
+    pa.h1x2 = 2.0f * fdot(Bp, lf.e01);
+    pa.h2x2 = 2.0f * fdot(Bp, lf.e03);
+    const float a10 = pa.h0 + pa.h1x2 + lf.g11, a01 = pa.h0 + pa.h2x2 + lf.g22;
+    const float a11 = a10 + pa.h2x2 + lf.g22 + lf.g12x2;
+    const float a_max = __builtin_fmaxf(__builtin_fmaxf(pa.h0, a10), __builtin_fmaxf(a01, a11));
+    const float pl = fdot(lf.nor, Bp);
+    const float nl2 = fdot(lf.nor, lf.nor);
+    const bool rec_ok = pl * pl > 1.0001e-6f * nl2 && a_max < 1e12f && nl2 > 1e-30f && nl2 < 1e30f;
+    if (!rec_ok) return 0u;
+    // lower bound of a: exact minimum over the square for a rectangle, else the squared distance to the light's plane
+    float a_min = (pl * pl) / nl2;
+    if (lf.g12x2 * lf.g12x2 <= 1e-12f * (lf.g11 * lf.g22)) {
+        const float us = __builtin_fminf(__builtin_fmaxf(-0.5f * pa.h1x2 / lf.g11, 0.0f), 1.0f);
+        const float vs = __builtin_fminf(__builtin_fmaxf(-0.5f * pa.h2x2 / lf.g22, 0.0f), 1.0f);
+        const float am = __builtin_fmaf(__builtin_fmaf(lf.g11, us, pa.h1x2), us, __builtin_fmaf(__builtin_fmaf(lf.g22, vs, pa.h2x2), vs, pa.h0));
+        a_min = __builtin_fmaxf(a_min, am);
+    }
+    a_min *= 0.9999f;
+    const uint64_t cand = shadow_candidates(sc, li, P);
+    bool undecided = false, have_sure = false;
+    const uint32_t n_geom = sc->n_geom;
+    for (uint32_t i = 0; i < n_geom; ++i) {
+        const bool mine = (cand >> i) & 1ull;
+        if (!__any(mine)) continue;
+        const DevGeomHot CRT_CONST* g = &sc->hot[i];
+        const bool glass = g->mat_type == CRT_MAT_REFRACTIVE;
+        bool all_free = false, all_sure = false;
+        if (g->kind == CRT_GEOM_SPHERE) {
+            const SphSlot s = make_sph_slot(P, ld3c(g->o), g->n[0], Bp, lf, pa, a_max);
+            const float q00 = s.b0, q10 = s.b0 + s.b1, q01 = s.b0 + s.b2, q11 = q10 + s.b2;
+            const float bqmin = __builtin_fminf(__builtin_fminf(q00, q10), __builtin_fminf(q01, q11));
+            const float bqmax = __builtin_fmaxf(__builtin_fmaxf(q00, q10), __builtin_fmaxf(q01, q11));
+            // disc around the centre of the square
+            const float c0 = __builtin_fmaf(0.25f, s.A + s.B + s.C, __builtin_fmaf(0.5f, s.Du + s.Ev, s.F));
+            const float cu = s.A + 0.5f * s.B + s.Du, cv = s.C + 0.5f * s.B + s.Ev;
+            const float lin = 0.5f * (__builtin_fabsf(cu) + __builtin_fabsf(cv));
+            const float qb = 0.25f * __builtin_fabsf(s.B);
+            const float ub = c0 + lin + qb + 0.25f * (__builtin_fmaxf(s.A, 0.0f) + __builtin_fmaxf(s.C, 0.0f));
+            const float lb = c0 - lin - qb + 0.25f * (__builtin_fminf(s.A, 0.0f) + __builtin_fminf(s.C, 0.0f));
+            all_free = bqmin > s.kb || ub < -s.M;
+            all_sure = lb > s.M2 && bqmax < -s.kc;
+        } else if (sc->quad_par[li][i] != 0u) {
+            const DevGeomBox CRT_CONST* bx = &sc->box[i];
+            const QuadParSlot q = make_quad_par_slot(P, ld3c(g->o), ld3c(g->n), bx->sp_min2, bx->n2, ld3c(bx->mid), Bp, lf);
+            const float hout[3] = {bx->half_out[0], bx->half_out[1], bx->half_out[2]};
+            const float hin[3] = {bx->half_in[0], bx->half_in[1], bx->half_in[2]};
+            bool out_all = false, in_all = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float r00 = q.r[k][0], r10 = r00 + q.r[k][1], r01 = r00 + q.r[k][2], r11 = r10 + q.r[k][2];
+                const float rmin = __builtin_fminf(__builtin_fminf(r00, r10), __builtin_fminf(r01, r11));
+                const float rmax = __builtin_fmaxf(__builtin_fmaxf(r00, r10), __builtin_fmaxf(r01, r11));
+                out_all = out_all || rmin > hout[k] || rmax < -hout[k];
+                in_all = in_all && rmin > -hin[k] && rmax < hin[k];
+            }
+            const bool steep_all = a_max < q.t_steep;
+            all_free = q.behind || a_max < q.t_lift || a_min > q.t_beyond || (out_all && steep_all);
+            all_sure = in_all && steep_all && a_min > q.t_between;
+        }
+        if (mine) {
+            if (glass) {
+                if (!all_free) undecided = true;
+            } else {
+                if (all_sure) have_sure = true;
+                else if (!all_free) undecided = true;
+            }
+        }
+    }
+    if (undecided) return 0u;
+    return have_sure ? 2u : 1u;
+}
+
+// ---------------------------------------------------------------------------------------- trace
+__global__ void __launch_bounds__(64, 4) wf_trace_kernel(WfArgs w, uint32_t first) {
+    const RenderArgs& a = w.r;
+    ScenePtr sc = (ScenePtr)a.scene;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t unit = blockIdx.x;
+    const size_t n_lp = w.n_lp;
+    const size_t lp = (size_t)unit * 64u + lane;
+    const uint32_t npix = a.nx * a.ny;
+    const PixelMap pm = map_pixel(a, unit, lane);
+    const uint32_t pix = pm.valid ? pm.j * a.nx + pm.i : 0u;
+
+    // get_world_coordinates (main.cu:306-314) and pixel_size (main.cu:337)
+    const float height_world = 2.0f;
+    const float width_world = height_world * ((float)a.nx / (float)a.ny);
+    const float pix_w = width_world / (float)a.nx, pix_h = height_world / (float)a.ny;
+    // Camera::getRay constants (Camera.hpp:97-98,133-134)
+    const V3 cam_pos = ld3c(sc->cam.pos), cam_front = ld3c(sc->cam.front), cam_right = ld3c(sc->cam.right),
+             cam_up = ld3c(sc->cam.up);
+    const V3 eye = cam_pos - cam_front * (width_world * 0.5f * sc->cam.one_over_tan);
+    const uint32_t cam_type = sc->cam.type;
+    float ortho;
+    {
+        float aspect = height_world / width_world;
+        ortho = sc->cam.ortho_scale * (aspect > 1.0f ? aspect : 1.0f);
+    }
+    const uint32_t aa_iter = a.aa_iter;                // 0 or 1 here
+    const uint32_t n_calls = aa_iter == 0u ? 1u : 4u;  // color() calls per pixel (main.cu:254-268)
+    const float inv_ind = 1.0f / (float)a.ind_rays;    // main.cu:182
+    // generator draws one diffuse hit consumes in LightList::calculateColor (AreaLight.hpp:342-343,495)
+    uint32_t skip_draws = 0;
+    for (uint32_t li = 0; li < sc->n_lights; ++li) {
+        const DevLight CRT_CONST* L = &sc->lights[li];
+        if (L->kind == CRT_LIGHT_AREA && L->initialized) skip_draws += 2u * L->shadow_samples;
+    }
+
+    // ---- traversal state
+    uint32_t ctl = 0;
+    if (!first) ctl = w.state[ST_CTL * n_lp + lp];
+    bool done = !pm.valid || (ctl & 1u);
+    const bool live_at_entry = !done;
+    bool color_active = (ctl >> 1) & 1u, cur_valid = (ctl >> 2) & 1u;
+    uint32_t call = (ctl >> 4) & 15u, nframes = (ctl >> 8) & 15u;
+    Rng rng = {0, 0, 0, 0, 0, 0};
+    V3 cur_o = mk3(0, 0, 0), cur_d = mk3(0, 0, 0), ray_d = mk3(0.0f, 0.0f, -1.0f);
+    V4 cur_att = V4{1, 1, 1, 1};
+    uint32_t cur_ref = 0, cur_depth = 0, on_stack = 0;
+    if (live_at_entry) {
+        rng.v0 = a.rng[0 * (size_t)npix + pix];
+        rng.v1 = a.rng[1 * (size_t)npix + pix];
+        rng.v2 = a.rng[2 * (size_t)npix + pix];
+        rng.v3 = a.rng[3 * (size_t)npix + pix];
+        rng.v4 = a.rng[4 * (size_t)npix + pix];
+        rng.d = a.rng[5 * (size_t)npix + pix];
+        if (!first) {
+            const uint32_t* s = w.state + lp;
+            cur_o = mk3(u2f(s[(ST_CUR_O + 0) * n_lp]), u2f(s[(ST_CUR_O + 1) * n_lp]), u2f(s[(ST_CUR_O + 2) * n_lp]));
+            cur_d = mk3(u2f(s[(ST_CUR_D + 0) * n_lp]), u2f(s[(ST_CUR_D + 1) * n_lp]), u2f(s[(ST_CUR_D + 2) * n_lp]));
+            cur_att = V4{u2f(s[(ST_CUR_ATT + 0) * n_lp]), u2f(s[(ST_CUR_ATT + 1) * n_lp]),
+                         u2f(s[(ST_CUR_ATT + 2) * n_lp]), u2f(s[(ST_CUR_ATT + 3) * n_lp])};
+            cur_ref = s[ST_CUR_REF * n_lp];
+            cur_depth = s[ST_CUR_DEPTH * n_lp];
+            ray_d = mk3(u2f(s[(ST_RAY_D + 0) * n_lp]), u2f(s[(ST_RAY_D + 1) * n_lp]), u2f(s[(ST_RAY_D + 2) * n_lp]));
+            on_stack = s[ST_ON_STACK * n_lp];
+        }
+    }
+    // remap<float,true> (math_functions.hpp:31-45)
+    float x_world, y_world;
+    {
+        float denom = (float)a.nx - 0.0f;
+        float es = -width_world * 0.5f, ee = width_world * 0.5f;
+        x_world = (denom == 0.0f) ? (float)pm.i : es + ((ee - es) / denom) * ((float)pm.i - 0.0f);
+        float denomy = (float)a.ny - 0.0f;
+        y_world = (denomy == 0.0f) ? (float)pm.j : 1.0f + ((-1.0f - 1.0f) / denomy) * ((float)pm.j - 0.0f);
+    }
+
+    uint32_t cnt = 0; // result slots filled this round
+    uint32_t cnt_shade = 0, cnt_expand = 0;
+    const uint32_t quota = w.quota;
+    // Shade records are handed out to the wave in chunks of kWorkChunk consecutive indices, so the one
+    // global counter sees one atomic per chunk instead of one per step.
+    // Two streams share the record array: records whose visibility is already decided for every light
+    // (record_light_class) fill it from index 0 upwards and skip the filter and resolve kernels; records
+    // that need their samples looked at fill it from the top downwards (logical position p = index
+    // cap_work - 1 - p).
+    uint32_t chunk_base[2] = {0, 0}, chunk_used[2] = {kWorkChunk, kWorkChunk}; // wave-uniform; [0] decided, [1] to sample
+    bool have_chunk[2] = {false, false};
+
+    for (;;) {
+        const bool go = !done && cnt < quota;
+        if (!__any(go)) break;
+        bool emit = false; // a diffuse hit to record
+        V3 n_P = mk3(0, 0, 0), n_N = mk3(0, 0, 0), n_view = mk3(0, 0, 0);
+        V4 n_att = V4{0, 0, 0, 0};
+        uint32_t n_geom = 0, n_depth = 0;
+        if (go) {
+            if (!cur_valid) {
+                if (!color_active) {
+                    if (call == n_calls) {
+                        // render() epilogue (main.cu:339-346) happens in the sum kernel
+                        w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_END_PIXEL;
+                        ++cnt;
+                        done = true;
+                    } else {
+                        // aa_color (main.cu:230-304): level-0 task = pixel centre, level-1 task = 4 corners
+                        float rx, ry;
+                        if (aa_iter == 0u) {
+                            rx = x_world;
+                            ry = y_world;
+                        } else {
+                            float hx = pix_w * 0.5f, hy = pix_h * 0.5f;
+                            float ox = (call & 1u) ? 1.0f : -1.0f, oy = (call & 2u) ? 1.0f : -1.0f;
+                            rx = x_world + ox * hx * 0.5f;
+                            ry = y_world + oy * hy * 0.5f;
+                        }
+                        // Camera::getRay (Camera.hpp:86-144)
+                        V3 ro, rd;
+                        if (cam_type == CRT_CAM_ORTHOGRAPHIC) {
+                            ro = ((cam_right * rx) * ortho + (cam_up * ry) * ortho) + cam_pos;
+                            rd = ray_dir(cam_front);
+                        } else {
+                            ro = (cam_right * rx + cam_up * ry) + cam_pos;
+                            rd = ray_dir(ro - eye);
+                        }
+                        cur_o = ro;
+                        cur_d = rd;
+                        cur_att = V4{1.0f, 1.0f, 1.0f, 1.0f};
+                        cur_ref = a.ref_iter;
+                        cur_depth = a.gl_iter;
+                        cur_valid = true;
+                        color_active = true;
+                        ray_d = mk3(0.0f, 0.0f, -1.0f);
+                        nframes = 0;
+                        on_stack = 0;
+                    }
+                } else if (nframes == 0) {
+                    // color() returned (main.cu:225): the sum kernel folds it into the pixel
+                    w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_END_CALL;
+                    ++cnt;
+                    color_active = false;
+                    ++call;
+                } else {
+                    // pop the next child of the innermost frame (children leave last-to-first)
+                    uint32_t* f = w.frames + ((size_t)(nframes - 1u) * WF_FRAME_PLANES) * n_lp + lp;
+                    Rng rv;
+                    rv.v0 = f[(FR_RNG + 0) * n_lp];
+                    rv.v1 = f[(FR_RNG + 1) * n_lp];
+                    rv.v2 = f[(FR_RNG + 2) * n_lp];
+                    rv.v3 = f[(FR_RNG + 3) * n_lp];
+                    rv.v4 = f[(FR_RNG + 4) * n_lp];
+                    rv.d = f[(FR_RNG + 5) * n_lp];
+                    float r2 = rng_current_uniform(rv);
+                    rng_unstep(rv);
+                    float r1 = rng_current_uniform(rv);
+                    rng_unstep(rv);
+                    V3 hp = mk3(u2f(f[(FR_P + 0) * n_lp]), u2f(f[(FR_P + 1) * n_lp]), u2f(f[(FR_P + 2) * n_lp]));
+                    V3 hn = mk3(u2f(f[(FR_N + 0) * n_lp]), u2f(f[(FR_N + 1) * n_lp]), u2f(f[(FR_N + 2) * n_lp]));
+                    V4 patt = V4{u2f(f[(FR_ATT + 0) * n_lp]), u2f(f[(FR_ATT + 1) * n_lp]), u2f(f[(FR_ATT + 2) * n_lp]),
+                                 u2f(f[(FR_ATT + 3) * n_lp])};
+                    const uint32_t fgeom = f[FR_GEOM * n_lp];
+                    V4 pdiff = ld4c(sc->shade[fgeom].diffuse);
+                    const uint32_t cdepth = f[FR_CHILD_DEPTH * n_lp];
+                    uint32_t rem = f[FR_REMAINING * n_lp] - 1u;
+                    if (rem == 0u) {
+                        --nframes;
+                    } else {
+                        f[FR_REMAINING * n_lp] = rem;
+                        f[(FR_RNG + 0) * n_lp] = rv.v0;
+                        f[(FR_RNG + 1) * n_lp] = rv.v1;
+                        f[(FR_RNG + 2) * n_lp] = rv.v2;
+                        f[(FR_RNG + 3) * n_lp] = rv.v3;
+                        f[(FR_RNG + 4) * n_lp] = rv.v4;
+                        f[(FR_RNG + 5) * n_lp] = rv.d;
+                    }
+                    --on_stack;
+                    // get_random_ray_values_in_hemisphere (main.cu:60-74)
+                    V3 Nx, Nz;
+                    surface_frame(hn, Nx, Nz);
+                    const float PI_2 = 6.28318530717958647692f;
+                    float sinTheta = 1.0f - r1 * r1;
+                    float phi = r2 * PI_2;
+                    float sp, cp;
+                    sincos_c(phi, sp, cp);
+                    float x = sinTheta * cp, z = sinTheta * sp;
+                    V3 wd = mk3(x * Nz.x + r1 * hn.x + z * Nx.x, x * Nz.y + r1 * hn.y + z * Nx.y,
+                                x * Nz.z + r1 * hn.z + z * Nx.z);
+                    cur_o = hp + wd * 0.01f;
+                    cur_d = wd;
+                    cur_att = ((pdiff * (2.0f * r1)) * patt) * inv_ind; // main.cu:186
+                    cur_ref = a.ref_iter;
+                    cur_depth = cdepth;
+                    cur_valid = true;
+                }
+            }
+            if (cur_valid) {
+                // ---- pop (main.cu:132-147)
+                cur_valid = false;
+                if (cur_ref != 0u) {
+                    if (!eps_equal(len_sq(cur_d), 0.0f, kEpsSq)) ray_d = normalize3(cur_d);
+                    const V3 ro = cur_o;
+                    Hit h = closest_hit(sc, ro, ray_d, 0.0f);
+                    if (h.idx < 0) {
+                        // final_color += attenuation * Color::black() (main.cu:149-151)
+                        const V4 c = cur_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
+                        w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_ADD;
+                        w.contrib[(size_t)cnt * n_lp + lp] = make_float4(c.x, c.y, c.z, c.w);
+                        ++cnt;
+                    } else {
+                        V3 P, N;
+                        hit_point_normal(sc, h, ro, ray_d, P, N);
+                        if (h.mat_type == CRT_MAT_DIFFUSE) {
+                            emit = true;
+                            n_P = P;
+                            n_N = N;
+                            n_view = neg(cur_d); // viewDir = -state.r_dir, the stored (un-normalised) direction
+                            n_att = cur_att;
+                            n_geom = (uint32_t)h.idx;
+                            n_depth = cur_depth;
+                        } else if (h.mat_type == CRT_MAT_REFLECT) {
+                            // get_reflect_ray (main.cu:76-81)
+                            V3 I = normalize3(ray_d);
+                            V3 rdir = reflect3(I, normalize3(N));
+                            cur_o = P + rdir * 0.01f;
+                            cur_d = rdir;
+                            cur_att = cur_att * ld4c(sc->shade[h.idx].diffuse);
+                            cur_ref = cur_ref - 1u;
+                            cur_valid = true;
+                        } else {
+                            // get_refraction_ray (main.cu:83-108)
+                            bool front_face = dot3(ray_d, N) < 0.0f;
+                            V3 norm = front_face ? N : neg(N);
+                            float ratio = sc->shade[h.idx].refract_index / 1.0f;
+                            if (front_face) ratio = rcp_exact(ratio);
+                            V3 rdn = normalize3(ray_d);
+                            float cos_theta = __builtin_fminf(dot3(neg(rdn), norm), 1.0f);
+                            float sin_theta = rcp_exact(rsqrt_c(1.0f - cos_theta * cos_theta));
+                            bool cannot_refract = ratio * sin_theta > 1.0f; // reflectance(...) > 1 never holds
+                            V3 dir = cannot_refract ? reflect3(rdn, norm) : refract3(rdn, norm, ratio);
+                            cur_o = P + dir * 0.01f;
+                            cur_d = dir;
+                            cur_att = cur_att * ld4c(sc->shade[h.idx].diffuse);
+                            cur_ref = cur_ref - 1u;
+                            cur_valid = true;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- record the diffuse hits of this step (all lanes are here together)
+        const uint64_t em = __ballot(emit);
+        if (em != 0) {
+            // visibility class per light (wave-uniform loop over lights, per-lane result)
+            bool decided = true;
+            uint32_t dark_lights = 0; // bit li: every shadow ray towards light li is blocked
+            for (uint32_t li = 0; li < sc->n_lights; ++li) {
+                const DevLight CRT_CONST* L = &sc->lights[li];
+                if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue;
+                const LightF lf = load_lightf(L);
+                const uint32_t c = record_light_class(sc, li, lf, n_P);
+                if (c == 0u) decided = false;
+                if (c == 2u) dark_lights |= 1u << li;
+            }
+            uint32_t my_wi = 0;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const uint64_t sm = __ballot(emit && (decided == (st == 0)));
+                if (sm == 0) continue;
+                const uint32_t n_emit = (uint32_t)__popcll(sm);
+                const bool need_chunk = chunk_used[st] + n_emit > kWorkChunk;
+                uint32_t new_base = 0;
+                if (need_chunk) {
+                    if (lane == (uint32_t)__builtin_ctzll(sm))
+                        new_base = atomicAdd(&w.ctrs[st == 0 ? WF_CTR_WORK : WF_CTR_WORK_SAMPLED], kWorkChunk);
+                    new_base = (uint32_t)__builtin_amdgcn_readlane((int)new_base, __builtin_ctzll(sm));
+                }
+                const uint32_t my_pos = chunk_used[st] + lane_rank(sm);
+                const uint32_t logical = my_pos < kWorkChunk ? chunk_base[st] + my_pos : new_base + (my_pos - kWorkChunk);
+                if (emit && (decided == (st == 0))) my_wi = st == 0 ? logical : w.cap_work - 1u - logical;
+                if (need_chunk) {
+                    chunk_base[st] = new_base;
+                    chunk_used[st] = chunk_used[st] + n_emit - kWorkChunk;
+                    have_chunk[st] = true;
+                } else {
+                    chunk_used[st] += n_emit;
+                }
+            }
+            if (emit) {
+                const uint32_t wi = my_wi;
+                const uint32_t slot_k = cnt;
+                w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_ADD;
+                ++cnt;
+                ++cnt_shade;
+                if (wi < w.cap_work) {
+                    uint32_t* r = w.work + wi;
+                    const size_t cw = w.cap_work;
+                    r[(WK_P + 0) * cw] = f2u(n_P.x);
+                    r[(WK_P + 1) * cw] = f2u(n_P.y);
+                    r[(WK_P + 2) * cw] = f2u(n_P.z);
+                    r[(WK_N + 0) * cw] = f2u(n_N.x);
+                    r[(WK_N + 1) * cw] = f2u(n_N.y);
+                    r[(WK_N + 2) * cw] = f2u(n_N.z);
+                    r[(WK_V + 0) * cw] = f2u(n_view.x);
+                    r[(WK_V + 1) * cw] = f2u(n_view.y);
+                    r[(WK_V + 2) * cw] = f2u(n_view.z);
+                    r[(WK_ATT + 0) * cw] = f2u(n_att.x);
+                    r[(WK_ATT + 1) * cw] = f2u(n_att.y);
+                    r[(WK_ATT + 2) * cw] = f2u(n_att.z);
+                    r[(WK_ATT + 3) * cw] = f2u(n_att.w);
+                    r[WK_GEOM * cw] = n_geom;
+                    r[(WK_RNG + 0) * cw] = rng.v0;
+                    r[(WK_RNG + 1) * cw] = rng.v1;
+                    r[(WK_RNG + 2) * cw] = rng.v2;
+                    r[(WK_RNG + 3) * cw] = rng.v3;
+                    r[(WK_RNG + 4) * cw] = rng.v4;
+                    r[(WK_RNG + 5) * cw] = rng.d;
+                    r[WK_SLOT * cw] = (uint32_t)((size_t)slot_k * n_lp + lp);
+                    if (decided) {
+                        for (uint32_t li = 0; li < sc->n_lights; ++li) {
+                            const DevLight CRT_CONST* L = &sc->lights[li];
+                            if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue;
+                            w.shadow_cnt[(size_t)li * cw + wi] = ((dark_lights >> li) & 1u) ? L->shadow_samples : 0u;
+                        }
+                    }
+                } else {
+                    w.ctrs[WF_CTR_ERROR] = 1u;
+                }
+                // the light samples of this hit (drawn by the filter kernel from the recorded state)
+                for (uint32_t k = 0; k < skip_draws; ++k) rng_step(rng);
+                if (n_depth > 0u) {
+                    ++cnt_expand;
+                    // The reference draws (r1,r2) for every child and pushes while its stack has room (main.cu:176-191).
+                    uint32_t room = on_stack < CRT_RAY_STACK ? CRT_RAY_STACK - on_stack : 0u;
+                    uint32_t accepted = a.ind_rays < room ? a.ind_rays : room;
+                    for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
+                    if (accepted > 0u) {
+                        uint32_t* f = w.frames + ((size_t)nframes * WF_FRAME_PLANES) * n_lp + lp;
+                        ++nframes;
+                        f[(FR_P + 0) * n_lp] = f2u(n_P.x);
+                        f[(FR_P + 1) * n_lp] = f2u(n_P.y);
+                        f[(FR_P + 2) * n_lp] = f2u(n_P.z);
+                        f[(FR_N + 0) * n_lp] = f2u(n_N.x);
+                        f[(FR_N + 1) * n_lp] = f2u(n_N.y);
+                        f[(FR_N + 2) * n_lp] = f2u(n_N.z);
+                        f[(FR_ATT + 0) * n_lp] = f2u(n_att.x);
+                        f[(FR_ATT + 1) * n_lp] = f2u(n_att.y);
+                        f[(FR_ATT + 2) * n_lp] = f2u(n_att.z);
+                        f[(FR_ATT + 3) * n_lp] = f2u(n_att.w);
+                        f[(FR_RNG + 0) * n_lp] = rng.v0;
+                        f[(FR_RNG + 1) * n_lp] = rng.v1;
+                        f[(FR_RNG + 2) * n_lp] = rng.v2;
+                        f[(FR_RNG + 3) * n_lp] = rng.v3;
+                        f[(FR_RNG + 4) * n_lp] = rng.v4;
+                        f[(FR_RNG + 5) * n_lp] = rng.d;
+                        f[FR_GEOM * n_lp] = n_geom;
+                        f[FR_REMAINING * n_lp] = accepted;
+                        f[FR_CHILD_DEPTH * n_lp] = n_depth - 1u;
+                        on_stack += accepted;
+                    }
+                    for (uint32_t k = 2u * accepted; k < 2u * a.ind_rays; ++k) rng_step(rng);
+                }
+            }
+        }
+    }
+
+    // ---- the unused tail of the last chunk holds no record
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+        if (have_chunk[st])
+            for (uint32_t k = chunk_used[st] + lane; k < kWorkChunk; k += 64u) {
+                const uint32_t logical = chunk_base[st] + k;
+                if (logical < w.cap_work)
+                    w.work[(size_t)WK_GEOM * w.cap_work + (st == 0 ? logical : w.cap_work - 1u - logical)] = kNoRecord;
+            }
+
+    // ---- park the traversal
+    w.slot_count[lp] = cnt;
+    if (live_at_entry) {
+        a.rng[0 * (size_t)npix + pix] = rng.v0;
+        a.rng[1 * (size_t)npix + pix] = rng.v1;
+        a.rng[2 * (size_t)npix + pix] = rng.v2;
+        a.rng[3 * (size_t)npix + pix] = rng.v3;
+        a.rng[4 * (size_t)npix + pix] = rng.v4;
+        a.rng[5 * (size_t)npix + pix] = rng.d;
+        a.counters[pix] += cnt_shade;
+        a.counters[npix + pix] += cnt_expand;
+        uint32_t* s = w.state + lp;
+        s[ST_CTL * n_lp] = (done ? 1u : 0u) | (color_active ? 2u : 0u) | (cur_valid ? 4u : 0u) | (call << 4) | (nframes << 8);
+        if (!done) {
+            s[(ST_CUR_O + 0) * n_lp] = f2u(cur_o.x);
+            s[(ST_CUR_O + 1) * n_lp] = f2u(cur_o.y);
+            s[(ST_CUR_O + 2) * n_lp] = f2u(cur_o.z);
+            s[(ST_CUR_D + 0) * n_lp] = f2u(cur_d.x);
+            s[(ST_CUR_D + 1) * n_lp] = f2u(cur_d.y);
+            s[(ST_CUR_D + 2) * n_lp] = f2u(cur_d.z);
+            s[(ST_CUR_ATT + 0) * n_lp] = f2u(cur_att.x);
+            s[(ST_CUR_ATT + 1) * n_lp] = f2u(cur_att.y);
+            s[(ST_CUR_ATT + 2) * n_lp] = f2u(cur_att.z);
+            s[(ST_CUR_ATT + 3) * n_lp] = f2u(cur_att.w);
+            s[ST_CUR_REF * n_lp] = cur_ref;
+            s[ST_CUR_DEPTH * n_lp] = cur_depth;
+            s[(ST_RAY_D + 0) * n_lp] = f2u(ray_d.x);
+            s[(ST_RAY_D + 1) * n_lp] = f2u(ray_d.y);
+            s[(ST_RAY_D + 2) * n_lp] = f2u(ray_d.z);
+            s[ST_ON_STACK * n_lp] = on_stack;
+        }
+    } else if (first) {
+        w.state[ST_CTL * n_lp + lp] = 1u; // pixel slots outside the image never run
+    }
+    const uint64_t alive = __ballot(!done);
+    if (lane == 0 && alive != 0) atomicAdd(&w.ctrs[WF_CTR_ACTIVE], (uint32_t)__popcll(alive));
+}
+
+// --------------------------------------------------------------------------------------- filter
 #ifndef CRT_WF_FILTER_WAVES
 #define CRT_WF_FILTER_WAVES 4
 #endif
@@ -1073,7 +1194,7 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
 // Test instrument: repeats the filter's classification for every shadow ray of the records in
 // [w_begin, w_end) and compares each decided ray with the exact test.  tallies[2] += decided rays,
 // tallies[3] += contradictions (must stay 0).
-__global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end) {
+__global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end, uint32_t decided_records) {
     ScenePtr sc = (ScenePtr)w.r.scene;
     const uint32_t lane = threadIdx.x;
     const size_t cw = w.cap_work;
@@ -1102,9 +1223,14 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
             for (uint32_t s = 0; s < S; ++s) {
                 const float u = rng_uniform(rng), v = rng_uniform(rng);
                 const float us[1] = {u}, vs[1] = {v};
-                const Classes k = classify_samples<1, false>(sc, lf, rf, us, vs);
-                const bool covered = k.sure_opaque && !k.maybe_glass;
-                const bool unresolved = !covered && (k.maybe_any || k.sure_opaque);
+                bool covered, unresolved = false;
+                if (decided_records) { // the trace kernel decided all samples of this record at once
+                    covered = w.shadow_cnt[(size_t)li * cw + wr] != 0u;
+                } else {
+                    const Classes k = classify_samples<1, false>(sc, lf, rf, us, vs);
+                    covered = k.sure_opaque && !k.maybe_glass;
+                    unresolved = !covered && (k.maybe_any || k.sure_opaque);
+                }
                 if (act && !unresolved) {
                     V3 o, d;
                     float x;
@@ -1237,10 +1363,10 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
 }
 
 // ---------------------------------------------------------------------------------------- shade
-__global__ void __launch_bounds__(64, 4) wf_shade_kernel(WfArgs w, uint32_t n_work) {
+__global__ void __launch_bounds__(64, 4) wf_shade_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end) {
     ScenePtr sc = (ScenePtr)w.r.scene;
-    const uint32_t wi = blockIdx.x * 64u + threadIdx.x;
-    if (wi >= n_work) return;
+    const uint32_t wi = w_begin + blockIdx.x * 64u + threadIdx.x;
+    if (wi >= w_end) return;
     const size_t cw = w.cap_work;
     const uint32_t* r = w.work + wi;
     const V3 P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
@@ -1348,8 +1474,8 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     uint64_t quota_max = budget_bytes / (per_slot * n_lp);
     if (quota_max < 16u) quota_max = 16u;
     if (want > quota_max) want = quota_max;
-    if ((want + kWorkChunk / 64u) * n_lp >= (1ull << 28)) { // record index and light share one word
-        want = ((1ull << 28) - 1u) / n_lp - kWorkChunk / 64u;
+    if ((want + 2u * kWorkChunk / 64u + 1u) * n_lp >= (1ull << 28)) { // record index and light share one word
+        want = ((1ull << 28) - 1u) / n_lp - 2u * kWorkChunk / 64u - 1u;
         if (want < 8u) return hipErrorOutOfMemory; // more than 2^25 pixel slots in one launch
     }
     const uint32_t quota = (uint32_t)want;
@@ -1360,7 +1486,8 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return e;
     wavefront_release(ws);
-    const uint32_t cap_work = quota * n_lp + args.n_units * kWorkChunk; // + every trace wave's partly used chunk
+    // + every trace wave's two partly used chunks; a multiple of the chunk size so that both streams stay aligned
+    const uint32_t cap_work = ((quota * n_lp + 2u * args.n_units * kWorkChunk + kWorkChunk - 1u) / kWorkChunk) * kWorkChunk;
     // every filter wave owns a region of the queue that holds all shadow rays of its records:
     // at most 2^30 rays (12.9 GB), less when all records of a round cast fewer
     uint64_t qwant = (uint64_t)cap_work * (args.max_shadow_rays ? args.max_shadow_rays : 1u) + 64ull * kMaxFilterWaves;
@@ -1458,22 +1585,30 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
-        const uint32_t n_work = ws.ctrs_host[WF_CTR_WORK];
+        const uint32_t n_decided = ws.ctrs_host[WF_CTR_WORK];         // records [0, n_decided)
+        const uint32_t n_sampled = ws.ctrs_host[WF_CTR_WORK_SAMPLED]; // records [cap_work - n_sampled, cap_work)
         const uint32_t n_active = ws.ctrs_host[WF_CTR_ACTIVE];
-        if (ws.ctrs_host[WF_CTR_ERROR] != 0u || n_work > ws.cap_work) {
+        if (ws.ctrs_host[WF_CTR_ERROR] != 0u || (uint64_t)n_decided + n_sampled > ws.cap_work) {
             *overflow = true;
             return hipSuccess;
         }
-        for (uint32_t b0 = 0; b0 < n_work; b0 += batch) {
-            const uint32_t b1 = n_work - b0 > batch ? b0 + batch : n_work;
+        const uint32_t s_begin = ws.cap_work - n_sampled;
+        for (uint32_t b0 = s_begin; b0 < ws.cap_work; b0 += batch) {
+            const uint32_t b1 = ws.cap_work - b0 > batch ? b0 + batch : ws.cap_work;
             const uint32_t groups = (b1 - b0 + 63u) / 64u;
             const uint32_t fgrid = groups < fwaves ? groups : fwaves;
             hipLaunchKernelGGL(wf_filter_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
-            if (args.audit) hipLaunchKernelGGL(wf_audit_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
+            if (args.audit) hipLaunchKernelGGL(wf_audit_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1, 0u);
             hipLaunchKernelGGL(wf_resolve_kernel, dim3(fgrid * kResolveSplit), dim3(64), 0, stream, w);
         }
-        if (n_work != 0u)
-            hipLaunchKernelGGL(wf_shade_kernel, dim3((n_work + 63u) / 64u), dim3(64), 0, stream, w, n_work);
+        if (args.audit && n_decided != 0u) {
+            const uint32_t groups = (n_decided + 63u) / 64u;
+            hipLaunchKernelGGL(wf_audit_kernel, dim3(groups < fwaves ? groups : fwaves), dim3(64), 0, stream, w, 0u, n_decided, 1u);
+        }
+        if (n_decided != 0u)
+            hipLaunchKernelGGL(wf_shade_kernel, dim3((n_decided + 63u) / 64u), dim3(64), 0, stream, w, 0u, n_decided);
+        if (n_sampled != 0u)
+            hipLaunchKernelGGL(wf_shade_kernel, dim3((n_sampled + 63u) / 64u), dim3(64), 0, stream, w, s_begin, ws.cap_work);
         hipLaunchKernelGGL(wf_sum_kernel, dim3(args.n_units), dim3(64), 0, stream, w, first);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
