@@ -212,6 +212,34 @@ DI void rng_unstep(Rng& s) {
     s.d -= 362437u;
 }
 
+// n steps at once.  The five xorshift words evolve linearly over GF(2), so the state after n steps is
+// the XOR of per-nibble table entries: tab[w][(word * 8 + nibble) * 16 + value] is word w of the image of
+// that nibble value (40 nibbles, 640 entries per plane, built on the host by stepping basis states);
+// the Weyl word just advances by n * 362437.
+constexpr uint32_t kJumpPlane = 640, kJumpWords = 5 * kJumpPlane;
+DI void rng_jump(Rng& s, const uint32_t* tab, uint32_t weyl_step) {
+    const uint32_t in[5] = {s.v0, s.v1, s.v2, s.v3, s.v4};
+    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+#pragma unroll
+    for (int wd = 0; wd < 5; ++wd) {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const uint32_t idx = (uint32_t)(wd * 8 + nb) * 16u + ((in[wd] >> (4 * nb)) & 15u);
+            o0 ^= tab[idx];
+            o1 ^= tab[kJumpPlane + idx];
+            o2 ^= tab[2 * kJumpPlane + idx];
+            o3 ^= tab[3 * kJumpPlane + idx];
+            o4 ^= tab[4 * kJumpPlane + idx];
+        }
+    }
+    s.v0 = o0;
+    s.v1 = o1;
+    s.v2 = o2;
+    s.v3 = o3;
+    s.v4 = o4;
+    s.d += weyl_step;
+}
+
 // ------------------------------------------------------------------ sin / cos
 // Stand-in for __sinf/__cosf on [0, 2*pi] (main.cu:64-65): two-term Cody-Waite
 // reduction by pi/2 and fixed polynomial kernels, mul/add only, so the host

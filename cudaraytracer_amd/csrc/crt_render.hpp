@@ -53,6 +53,8 @@ struct WfWorkspace {
     uint32_t* work = nullptr;       // [WF_WORK_PLANES][cap_work]
     uint32_t* shadow_cnt = nullptr; // [n_lights][cap_work]
     uint32_t* queue = nullptr;      // [3][qcap]
+    uint32_t* jump_dev = nullptr;   // two generator jump tables
+    uint32_t jump_n[2] = {0, 0};    // step counts the tables were built for
     uint32_t* qcounts = nullptr;    // entries per filter wave
     size_t bytes = 0;
 };

@@ -28,6 +28,8 @@
 // reference, so results are bit-identical to the single-kernel path in crt_render.hip.
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "crt_device.hpp"
 #include "crt_render.hpp"
 #include "crt_shade.hpp"
@@ -64,6 +66,8 @@ struct WfArgs {
     float4* px_acc;
     uint32_t* work;
     uint32_t* shadow_cnt;
+    const uint32_t* jump_tabs; // two rng_jump tables: [0] for jump_n[0] = draws per shaded point, [1] for jump_n[1] = 2 ind_rays
+    uint32_t jump_n[2];        // 0: no table
     uint32_t* queue;
     uint32_t* qcounts;    // entries each filter wave left in its region of the queue
     uint32_t region_cap;  // queue entries per filter wave
@@ -728,11 +732,17 @@ DI uint32_t record_light_class(ScenePtr sc, uint32_t li, const LightF& lf, V3 P)
 }
 
 // ---------------------------------------------------------------------------------------- trace
-__global__ void __launch_bounds__(64, 4) wf_trace_kernel(WfArgs w, uint32_t first) {
+constexpr uint32_t kTraceWaves = 4; // waves per trace workgroup (they share the generator jump tables in LDS)
+__global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w, uint32_t first) {
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t unit = blockIdx.x;
+    __shared__ uint32_t s_jump[2][kJumpWords];
+    for (uint32_t k = threadIdx.x; k < 2u * kJumpWords; k += 64u * kTraceWaves)
+        s_jump[k / kJumpWords][k % kJumpWords] = w.jump_tabs[k];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t unit = blockIdx.x * kTraceWaves + (threadIdx.x >> 6);
+    if (unit >= a.n_units) return;
     const size_t n_lp = w.n_lp;
     const size_t lp = (size_t)unit * 64u + lane;
     const uint32_t npix = a.nx * a.ny;
@@ -1054,13 +1064,15 @@ __global__ void __launch_bounds__(64, 4) wf_trace_kernel(WfArgs w, uint32_t firs
                     w.ctrs[WF_CTR_ERROR] = 1u;
                 }
                 // the light samples of this hit (drawn by the filter kernel from the recorded state)
-                for (uint32_t k = 0; k < skip_draws; ++k) rng_step(rng);
+                if (skip_draws != 0u && skip_draws == w.jump_n[0]) rng_jump(rng, s_jump[0], skip_draws * 362437u);
+                else for (uint32_t k = 0; k < skip_draws; ++k) rng_step(rng);
                 if (n_depth > 0u) {
                     ++cnt_expand;
                     // The reference draws (r1,r2) for every child and pushes while its stack has room (main.cu:176-191).
                     uint32_t room = on_stack < CRT_RAY_STACK ? CRT_RAY_STACK - on_stack : 0u;
                     uint32_t accepted = a.ind_rays < room ? a.ind_rays : room;
-                    for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
+                    if (accepted != 0u && 2u * accepted == w.jump_n[1]) rng_jump(rng, s_jump[1], 2u * accepted * 362437u);
+                    else for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
                     if (accepted > 0u) {
                         uint32_t* f = w.frames + ((size_t)nframes * WF_FRAME_PLANES) * n_lp + lp;
                         ++nframes;
@@ -1436,6 +1448,33 @@ __global__ void __launch_bounds__(64) wf_sum_kernel(WfArgs w, uint32_t first) {
 
 int g_resident_cus[64] = {0};
 
+// Table for rng_jump: images of every nibble value of every state word under `nsteps` XORWOW steps.
+void build_jump_table(uint32_t nsteps, uint32_t* tab) {
+    for (uint32_t pos = 0; pos < 40u; ++pos) {
+        uint32_t basis[4][5]; // images of the nibble's four bits
+        for (uint32_t bit = 0; bit < 4u; ++bit) {
+            uint32_t v[5] = {0, 0, 0, 0, 0};
+            v[pos / 8u] = 1u << (4u * (pos % 8u) + bit);
+            for (uint32_t n = 0; n < nsteps; ++n) { // the xorshift part of rng_step
+                const uint32_t t = v[0] ^ (v[0] >> 2);
+                v[0] = v[1];
+                v[1] = v[2];
+                v[2] = v[3];
+                v[3] = v[4];
+                v[4] = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+            }
+            for (int wd = 0; wd < 5; ++wd) basis[bit][wd] = v[wd];
+        }
+        for (uint32_t val = 0; val < 16u; ++val)
+            for (int wd = 0; wd < 5; ++wd) {
+                uint32_t x = 0;
+                for (uint32_t bit = 0; bit < 4u; ++bit)
+                    if ((val >> bit) & 1u) x ^= basis[bit][wd];
+                tab[(size_t)wd * kJumpPlane + pos * 16u + val] = x;
+            }
+    }
+}
+
 } // namespace
 
 bool wavefront_supports(const RenderArgs& args) { return args.aa_iter <= 1u; }
@@ -1452,6 +1491,7 @@ void wavefront_release(WfWorkspace& ws) {
     (void)hipFree(ws.work);
     (void)hipFree(ws.shadow_cnt);
     (void)hipFree(ws.queue);
+    (void)hipFree(ws.jump_dev);
     (void)hipFree(ws.qcounts);
     ws = WfWorkspace();
 }
@@ -1510,6 +1550,7 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     grab((void**)&ws.work, (size_t)WF_WORK_PLANES * cap_work * 4u);
     grab((void**)&ws.shadow_cnt, (size_t)lights * cap_work * 4u);
     grab((void**)&ws.queue, (size_t)3u * qcap * 4u);
+    grab((void**)&ws.jump_dev, (size_t)2u * kJumpWords * 4u);
     grab((void**)&ws.qcounts, (size_t)kMaxFilterWaves * 4u);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ws.ctrs_host, WF_CTR_COUNT * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -1558,6 +1599,9 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     w.work = ws.work;
     w.shadow_cnt = ws.shadow_cnt;
     w.queue = ws.queue;
+    w.jump_tabs = ws.jump_dev;
+    w.jump_n[0] = ws.jump_n[0];
+    w.jump_n[1] = ws.jump_n[1];
     w.qcounts = ws.qcounts;
     w.region_cap = 0;
 
@@ -1574,13 +1618,30 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     const uint32_t batch = batch64 > 0x40000000ull ? 0x40000000u : (uint32_t)batch64;
     w.region_cap = (uint32_t)(groups_per_wave * rays_per_group);
 
+    // generator jump tables for this scene and these settings
+    {
+        const uint32_t want[2] = {2u * args.max_shadow_rays, args.gl_iter ? 2u * args.ind_rays : 0u};
+        for (int t = 0; t < 2; ++t) {
+            if (ws.jump_n[t] == want[t]) continue;
+            std::vector<uint32_t> tab(kJumpWords, 0u);
+            if (want[t] != 0u) build_jump_table(want[t], tab.data());
+            e = hipMemcpyAsync(ws.jump_dev + (size_t)t * kJumpWords, tab.data(), kJumpWords * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream); // `tab` is pageable and about to go out of scope
+            if (e != hipSuccess) return e;
+            ws.jump_n[t] = want[t];
+        }
+        w.jump_n[0] = ws.jump_n[0];
+        w.jump_n[1] = ws.jump_n[1];
+    }
     uint32_t first = 1u;
     e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_COUNT * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     for (;;) {
         e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_ERROR * sizeof(uint32_t), stream); // the error word is sticky
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(wf_trace_kernel, dim3(args.n_units), dim3(64), 0, stream, w, first);
+        hipLaunchKernelGGL(wf_trace_kernel, dim3((args.n_units + kTraceWaves - 1u) / kTraceWaves), dim3(64 * kTraceWaves), 0,
+                           stream, w, first);
         e = hipMemcpyAsync(ws.ctrs_host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(stream);
