@@ -60,8 +60,7 @@ struct WfWorkspace {
 };
 constexpr uint32_t WF_STATE_PLANES = 17, WF_FRAME_PLANES = 19, WF_WORK_PLANES = 21;
 enum WfCounter : uint32_t {
-    WF_CTR_WORK = 0,    // shade records emitted this round whose visibility is already decided (array bottom)
-    WF_CTR_WORK_SAMPLED = 2, // shade records emitted this round that need the filter (array top)
+    WF_CTR_WORK = 0,    // shade records emitted this round
     WF_CTR_ACTIVE = 1,  // pixels not finished after this round
     WF_CTR_ERROR = 5,   // non-zero: a capacity was exceeded (results invalid)
     WF_CTR_COUNT = 16,

@@ -818,12 +818,8 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
     const uint32_t quota = w.quota;
     // Shade records are handed out to the wave in chunks of kWorkChunk consecutive indices, so the one
     // global counter sees one atomic per chunk instead of one per step.
-    // Two streams share the record array: records whose visibility is already decided for every light
-    // (record_light_class) fill it from index 0 upwards and skip the filter and resolve kernels; records
-    // that need their samples looked at fill it from the top downwards (logical position p = index
-    // cap_work - 1 - p).
-    uint32_t chunk_base[2] = {0, 0}, chunk_used[2] = {kWorkChunk, kWorkChunk}; // wave-uniform; [0] decided, [1] to sample
-    bool have_chunk[2] = {false, false};
+    uint32_t chunk_base = 0, chunk_used = kWorkChunk; // wave-uniform
+    bool have_chunk = false;
 
     for (;;) {
         const bool go = !done && cnt < quota;
@@ -988,40 +984,21 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
         // ---- record the diffuse hits of this step (all lanes are here together)
         const uint64_t em = __ballot(emit);
         if (em != 0) {
-            // visibility class per light (wave-uniform loop over lights, per-lane result)
-            bool decided = true;
-            uint32_t dark_lights = 0; // bit li: every shadow ray towards light li is blocked
-            for (uint32_t li = 0; li < sc->n_lights; ++li) {
-                const DevLight CRT_CONST* L = &sc->lights[li];
-                if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue;
-                const LightF lf = load_lightf(L);
-                const uint32_t c = record_light_class(sc, li, lf, n_P);
-                if (c == 0u) decided = false;
-                if (c == 2u) dark_lights |= 1u << li;
+            const uint32_t n_emit = (uint32_t)__popcll(em);
+            const bool need_chunk = chunk_used + n_emit > kWorkChunk;
+            uint32_t new_base = 0;
+            if (need_chunk) {
+                if (lane == (uint32_t)__builtin_ctzll(em)) new_base = atomicAdd(&w.ctrs[WF_CTR_WORK], kWorkChunk);
+                new_base = (uint32_t)__builtin_amdgcn_readlane((int)new_base, __builtin_ctzll(em));
             }
-            uint32_t my_wi = 0;
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const uint64_t sm = __ballot(emit && (decided == (st == 0)));
-                if (sm == 0) continue;
-                const uint32_t n_emit = (uint32_t)__popcll(sm);
-                const bool need_chunk = chunk_used[st] + n_emit > kWorkChunk;
-                uint32_t new_base = 0;
-                if (need_chunk) {
-                    if (lane == (uint32_t)__builtin_ctzll(sm))
-                        new_base = atomicAdd(&w.ctrs[st == 0 ? WF_CTR_WORK : WF_CTR_WORK_SAMPLED], kWorkChunk);
-                    new_base = (uint32_t)__builtin_amdgcn_readlane((int)new_base, __builtin_ctzll(sm));
-                }
-                const uint32_t my_pos = chunk_used[st] + lane_rank(sm);
-                const uint32_t logical = my_pos < kWorkChunk ? chunk_base[st] + my_pos : new_base + (my_pos - kWorkChunk);
-                if (emit && (decided == (st == 0))) my_wi = st == 0 ? logical : w.cap_work - 1u - logical;
-                if (need_chunk) {
-                    chunk_base[st] = new_base;
-                    chunk_used[st] = chunk_used[st] + n_emit - kWorkChunk;
-                    have_chunk[st] = true;
-                } else {
-                    chunk_used[st] += n_emit;
-                }
+            const uint32_t my_pos = chunk_used + lane_rank(em);
+            const uint32_t my_wi = my_pos < kWorkChunk ? chunk_base + my_pos : new_base + (my_pos - kWorkChunk);
+            if (need_chunk) {
+                chunk_base = new_base;
+                chunk_used = chunk_used + n_emit - kWorkChunk;
+                have_chunk = true;
+            } else {
+                chunk_used += n_emit;
             }
             if (emit) {
                 const uint32_t wi = my_wi;
@@ -1053,13 +1030,6 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
                     r[(WK_RNG + 4) * cw] = rng.v4;
                     r[(WK_RNG + 5) * cw] = rng.d;
                     r[WK_SLOT * cw] = (uint32_t)((size_t)slot_k * n_lp + lp);
-                    if (decided) {
-                        for (uint32_t li = 0; li < sc->n_lights; ++li) {
-                            const DevLight CRT_CONST* L = &sc->lights[li];
-                            if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue;
-                            w.shadow_cnt[(size_t)li * cw + wi] = ((dark_lights >> li) & 1u) ? L->shadow_samples : 0u;
-                        }
-                    }
                 } else {
                     w.ctrs[WF_CTR_ERROR] = 1u;
                 }
@@ -1104,14 +1074,9 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
     }
 
     // ---- the unused tail of the last chunk holds no record
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-        if (have_chunk[st])
-            for (uint32_t k = chunk_used[st] + lane; k < kWorkChunk; k += 64u) {
-                const uint32_t logical = chunk_base[st] + k;
-                if (logical < w.cap_work)
-                    w.work[(size_t)WK_GEOM * w.cap_work + (st == 0 ? logical : w.cap_work - 1u - logical)] = kNoRecord;
-            }
+    if (have_chunk)
+        for (uint32_t k = chunk_used + lane; k < kWorkChunk; k += 64u)
+            if (chunk_base + k < w.cap_work) w.work[(size_t)WK_GEOM * w.cap_work + chunk_base + k] = kNoRecord;
 
     // ---- park the traversal
     w.slot_count[lp] = cnt;
@@ -1155,47 +1120,98 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
 #ifndef CRT_WF_FILTER_WAVES
 #define CRT_WF_FILTER_WAVES 4
 #endif
+constexpr uint32_t kRecQueueCap = 128; // < 64 left over + 64 new entries per group
+
+// Runs the sample loop of light `li` for up to 64 queued records (one per lane).
+DI void filter_batch(const WfArgs& w, ScenePtr sc, uint32_t li, const LightF& lf, uint32_t S, uint32_t (*rq)[kRecQueueCap],
+                     uint32_t& rqn, uint32_t (*stg)[kStageCap], Stage& st, uint32_t lane, uint32_t& tally) {
+    const uint32_t n = rqn < 64u ? rqn : 64u;
+    const uint32_t base = rqn - n;
+    __syncthreads();
+    const bool act = lane < n;
+    const uint32_t slot = base + (act ? lane : 0u); // idle lanes shadow the first entry and discard the result
+    const uint32_t wi = rq[0][slot];
+    const V3 P = mk3(u2f(rq[1][slot]), u2f(rq[2][slot]), u2f(rq[3][slot]));
+    Rng rng;
+    rng.v0 = rq[4][slot];
+    rng.v1 = rq[5][slot];
+    rng.v2 = rq[6][slot];
+    rng.v3 = rq[7][slot];
+    rng.v4 = rq[8][slot];
+    rng.d = rq[9][slot];
+    rqn = base;
+    __syncthreads();
+    const RecordFilter rf = make_record_filter(sc, li, lf, P);
+    uint32_t shadowed = 0;
+    const uint32_t key = wi | (li << 28);
+    uint32_t s = 0;
+    if (rf.poly && rf.rest_mask == 0) { // every candidate has a slot: the sample loop is polynomial evaluation only
+        for (; s + 5u <= S; s += 5u) filter_block<5, true>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
+        for (; s < S; ++s) filter_block<1, true>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
+    } else {
+        for (; s + 5u <= S; s += 5u) filter_block<5, false>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
+        for (; s < S; ++s) filter_block<1, false>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
+    }
+    if (act) w.shadow_cnt[(size_t)li * w.cap_work + wi] = shadowed;
+}
+
+// For every light: each group of 64 records is first classified as a whole (record_light_class, all
+// lanes busy); records whose samples have to be looked at are compacted through an LDS queue, and the
+// sample loop runs on full batches of 64 of them.
 __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end) {
     ScenePtr sc = (ScenePtr)w.r.scene;
     const uint32_t lane = threadIdx.x;
     __shared__ uint32_t stg[3][kStageCap];
+    __shared__ uint32_t rq[10][kRecQueueCap]; // record index, P, generator state at the light's first draw
     Stage st = {0u, 0u, 0u};
+    uint32_t rqn = 0; // wave-uniform fill of rq
     uint32_t tally = 0;
     const size_t cw = w.cap_work;
     const uint32_t n_lights = sc->n_lights;
-    for (uint32_t base = blockIdx.x * 64u; base < w_end - w_begin; base += gridDim.x * 64u) {
-        const uint32_t wi = w_begin + base + lane;
-        const uint32_t wr = wi < w_end ? wi : w_begin; // tail lanes shadow a valid index and discard the result
-        const bool act = wi < w_end && w.work[(size_t)WK_GEOM * cw + wr] != kNoRecord;
-        const uint32_t* r = w.work + wr;
-        const V3 P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
-        Rng rng;
-        rng.v0 = r[(WK_RNG + 0) * cw];
-        rng.v1 = r[(WK_RNG + 1) * cw];
-        rng.v2 = r[(WK_RNG + 2) * cw];
-        rng.v3 = r[(WK_RNG + 3) * cw];
-        rng.v4 = r[(WK_RNG + 4) * cw];
-        rng.d = r[(WK_RNG + 5) * cw];
-        for (uint32_t li = 0; li < n_lights; ++li) {
-            const DevLight CRT_CONST* L = &sc->lights[li];
-            if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue; // no draws (Light.hpp:92-111, AreaLight.hpp:586)
-            const uint32_t S = L->shadow_samples;
-            const LightF lf = load_lightf(L);
-            const RecordFilter rf = make_record_filter(sc, li, lf, P);
-            uint32_t shadowed = 0;
-            const uint32_t key = wi | (li << 28);
-            uint32_t s = 0;
-            if (rf.poly && rf.rest_mask == 0) { // every candidate has a slot: the sample loop is polynomial evaluation only
-                for (; s + 5u <= S; s += 5u)
-                    filter_block<5, true>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
-                for (; s < S; ++s) filter_block<1, true>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
-            } else {
-                for (; s + 5u <= S; s += 5u)
-                    filter_block<5, false>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
-                for (; s < S; ++s) filter_block<1, false>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
+    uint32_t draws_before = 0; // draws of one record that precede light li (AreaLight.hpp:342-343 per sample)
+    for (uint32_t li = 0; li < n_lights; ++li) {
+        const DevLight CRT_CONST* L = &sc->lights[li];
+        if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue; // no draws (Light.hpp:92-111, AreaLight.hpp:586)
+        const uint32_t S = L->shadow_samples;
+        const LightF lf = load_lightf(L);
+        for (uint32_t base = blockIdx.x * 64u; base < w_end - w_begin; base += gridDim.x * 64u) {
+            const uint32_t wi = w_begin + base + lane;
+            const uint32_t wr = wi < w_end ? wi : w_begin;
+            const bool act = wi < w_end && w.work[(size_t)WK_GEOM * cw + wr] != kNoRecord;
+            const uint32_t* r = w.work + wr;
+            const V3 P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
+            const uint32_t c = record_light_class(sc, li, lf, P);
+            if (act && c != 0u) w.shadow_cnt[(size_t)li * cw + wi] = (c == 2u) ? S : 0u;
+            const bool queue = act && c == 0u;
+            const uint64_t qm = __ballot(queue);
+            if (qm != 0) {
+                if (queue) {
+                    Rng rng;
+                    rng.v0 = r[(WK_RNG + 0) * cw];
+                    rng.v1 = r[(WK_RNG + 1) * cw];
+                    rng.v2 = r[(WK_RNG + 2) * cw];
+                    rng.v3 = r[(WK_RNG + 3) * cw];
+                    rng.v4 = r[(WK_RNG + 4) * cw];
+                    rng.d = r[(WK_RNG + 5) * cw];
+                    for (uint32_t k = 0; k < draws_before; ++k) rng_step(rng);
+                    const uint32_t slot = rqn + lane_rank(qm);
+                    rq[0][slot] = wi;
+                    rq[1][slot] = f2u(P.x);
+                    rq[2][slot] = f2u(P.y);
+                    rq[3][slot] = f2u(P.z);
+                    rq[4][slot] = rng.v0;
+                    rq[5][slot] = rng.v1;
+                    rq[6][slot] = rng.v2;
+                    rq[7][slot] = rng.v3;
+                    rq[8][slot] = rng.v4;
+                    rq[9][slot] = rng.d;
+                }
+                rqn += (uint32_t)__popcll(qm);
+                if (rqn >= 64u) filter_batch(w, sc, li, lf, S, rq, rqn, stg, st, lane, tally);
             }
-            if (act) w.shadow_cnt[(size_t)li * cw + wi] = shadowed;
         }
+        while (rqn != 0u) filter_batch(w, sc, li, lf, S, rq, rqn, stg, st, lane, tally);
+        draws_before += 2u * S;
     }
     if (st.fill != 0u) stage_flush(w, stg, st, st.fill, lane);
     if (lane == 0) w.qcounts[blockIdx.x] = st.written;
@@ -1206,7 +1222,7 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
 // Test instrument: repeats the filter's classification for every shadow ray of the records in
 // [w_begin, w_end) and compares each decided ray with the exact test.  tallies[2] += decided rays,
 // tallies[3] += contradictions (must stay 0).
-__global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end, uint32_t decided_records) {
+__global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end) {
     ScenePtr sc = (ScenePtr)w.r.scene;
     const uint32_t lane = threadIdx.x;
     const size_t cw = w.cap_work;
@@ -1232,12 +1248,13 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
             const LightF lf = load_lightf(L);
             const LightC lc = load_lightc(L);
             const RecordFilter rf = make_record_filter(sc, li, lf, P);
+            const uint32_t rec_class = record_light_class(sc, li, lf, P); // 1 all free, 2 all blocked, 0 per sample
             for (uint32_t s = 0; s < S; ++s) {
                 const float u = rng_uniform(rng), v = rng_uniform(rng);
                 const float us[1] = {u}, vs[1] = {v};
                 bool covered, unresolved = false;
-                if (decided_records) { // the trace kernel decided all samples of this record at once
-                    covered = w.shadow_cnt[(size_t)li * cw + wr] != 0u;
+                if (rec_class != 0u) { // all samples of this record were decided at once
+                    covered = rec_class == 2u;
                 } else {
                     const Classes k = classify_samples<1, false>(sc, lf, rf, us, vs);
                     covered = k.sure_opaque && !k.maybe_glass;
@@ -1527,7 +1544,7 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     if (e != hipSuccess) return e;
     wavefront_release(ws);
     // + every trace wave's two partly used chunks; a multiple of the chunk size so that both streams stay aligned
-    const uint32_t cap_work = ((quota * n_lp + 2u * args.n_units * kWorkChunk + kWorkChunk - 1u) / kWorkChunk) * kWorkChunk;
+    const uint32_t cap_work = ((quota * n_lp + args.n_units * kWorkChunk + kWorkChunk - 1u) / kWorkChunk) * kWorkChunk;
     // every filter wave owns a region of the queue that holds all shadow rays of its records:
     // at most 2^30 rays (12.9 GB), less when all records of a round cast fewer
     uint64_t qwant = (uint64_t)cap_work * (args.max_shadow_rays ? args.max_shadow_rays : 1u) + 64ull * kMaxFilterWaves;
@@ -1646,30 +1663,22 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
-        const uint32_t n_decided = ws.ctrs_host[WF_CTR_WORK];         // records [0, n_decided)
-        const uint32_t n_sampled = ws.ctrs_host[WF_CTR_WORK_SAMPLED]; // records [cap_work - n_sampled, cap_work)
+        const uint32_t n_work = ws.ctrs_host[WF_CTR_WORK];
         const uint32_t n_active = ws.ctrs_host[WF_CTR_ACTIVE];
-        if (ws.ctrs_host[WF_CTR_ERROR] != 0u || (uint64_t)n_decided + n_sampled > ws.cap_work) {
+        if (ws.ctrs_host[WF_CTR_ERROR] != 0u || n_work > ws.cap_work) {
             *overflow = true;
             return hipSuccess;
         }
-        const uint32_t s_begin = ws.cap_work - n_sampled;
-        for (uint32_t b0 = s_begin; b0 < ws.cap_work; b0 += batch) {
-            const uint32_t b1 = ws.cap_work - b0 > batch ? b0 + batch : ws.cap_work;
+        for (uint32_t b0 = 0; b0 < n_work; b0 += batch) {
+            const uint32_t b1 = n_work - b0 > batch ? b0 + batch : n_work;
             const uint32_t groups = (b1 - b0 + 63u) / 64u;
             const uint32_t fgrid = groups < fwaves ? groups : fwaves;
             hipLaunchKernelGGL(wf_filter_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
-            if (args.audit) hipLaunchKernelGGL(wf_audit_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1, 0u);
+            if (args.audit) hipLaunchKernelGGL(wf_audit_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
             hipLaunchKernelGGL(wf_resolve_kernel, dim3(fgrid * kResolveSplit), dim3(64), 0, stream, w);
         }
-        if (args.audit && n_decided != 0u) {
-            const uint32_t groups = (n_decided + 63u) / 64u;
-            hipLaunchKernelGGL(wf_audit_kernel, dim3(groups < fwaves ? groups : fwaves), dim3(64), 0, stream, w, 0u, n_decided, 1u);
-        }
-        if (n_decided != 0u)
-            hipLaunchKernelGGL(wf_shade_kernel, dim3((n_decided + 63u) / 64u), dim3(64), 0, stream, w, 0u, n_decided);
-        if (n_sampled != 0u)
-            hipLaunchKernelGGL(wf_shade_kernel, dim3((n_sampled + 63u) / 64u), dim3(64), 0, stream, w, s_begin, ws.cap_work);
+        if (n_work != 0u)
+            hipLaunchKernelGGL(wf_shade_kernel, dim3((n_work + 63u) / 64u), dim3(64), 0, stream, w, 0u, n_work);
         hipLaunchKernelGGL(wf_sum_kernel, dim3(args.n_units), dim3(64), 0, stream, w, first);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
