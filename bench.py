@@ -23,7 +23,7 @@ sys.path.insert(0, str(ROOT))
 
 # README.md:131-133 of the reference (RTX 4070 Ti SUPER), seconds per render
 README_4070TIS_S = {"gl0": 0.116, "gl1": 10.438, "gl2": 574.214}
-PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak (256 CU x 4 SIMD-32 x 2 flop x 2.4 GHz)
+PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak (needs packed v_pk_fma_f32; see peak_note)
 
 
 def algorithmic_flops(stats):
@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--nx", type=int, default=720)
     ap.add_argument("--ny", type=int, default=720)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--pipeline", choices=["auto", "wavefront", "persistent"], default="auto",
+                    help="kernels behind crt_render: auto = wavefront pipeline where it applies")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-rows", action="store_true", help="skip the extra gl0/gl2 README rows at N=1")
     args = ap.parse_args()
@@ -77,6 +79,7 @@ def main():
     import torch
     import torch.distributed as dist
     import cudaraytracer_amd as crt
+    import cudaraytracer_amd.abi  # noqa: F401
     from cudaraytracer_amd import distributed as shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,6 +98,8 @@ def main():
     nx, ny = args.nx, args.ny
     st = crt.make_settings(nx=nx, ny=ny, gl_iter=gl)
     ctx = crt.Context(local_rank)
+    ctx.set_pipeline({"auto": crt.abi.CRT_PIPELINE_AUTO, "wavefront": crt.abi.CRT_PIPELINE_WAVEFRONT,
+                      "persistent": crt.abi.CRT_PIPELINE_PERSISTENT}[args.pipeline])
     ctx.upload(crt.cornell_box(st.shadowSamples))
     stream = torch.cuda.current_stream(dev)
     ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
@@ -119,6 +124,7 @@ def main():
         step()
     sync()
     s0 = stats_dict(ctx.stats(st))
+    ctx.set_timing(True)  # per-kernel HIP events on the launch stream, accumulated inside the library
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync()
     t0 = time.perf_counter()
@@ -135,7 +141,11 @@ def main():
     elapsed = time.perf_counter() - t0
     s1 = stats_dict(ctx.stats(st))
     work = diff(s0, s1)  # this rank's work over the K timed steps
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # render kernel, HIP events on its stream
+    render_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # whole crt_render call, HIP events on its stream
+    ktimes = {k: (ms / args.steps, n / args.steps) for k, (ms, n) in ctx.kernel_times().items() if n}
+    ctx.set_timing(False)
+    # GPU time of the kernels of one render: the wavefront kernels' own events, or the single persistent kernel
+    kernel_ms = sum(ms for ms, _ in ktimes.values()) if ktimes else render_ms
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -179,7 +189,11 @@ def main():
                        "primary_samples_per_s": nx * ny * 4 / (elapsed / args.steps)},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "crt::render_kernel", "kernel_ms": kernel_ms,
+                         "kernel": ("wavefront pipeline (" + "+".join(ktimes) + ")") if ktimes else "crt::render_kernel",
+                         "kernel_ms": kernel_ms, "render_call_ms": render_ms,
+                         "kernels": {k: {"ms": ms, "launches": n} for k, (ms, n) in ktimes.items()},
+                         "peak_note": "157.3 = 256 CU x 4 SIMD x 16 lanes/clk x 2 (packed v_pk_fma_f32) x 2 flop x 2.4 GHz; "
+                                      "a plain wave64 VALU instruction issues every 4 cycles per SIMD (78.6 TFLOP/s for unpacked fma)",
                          "flops_model": "300*shadow_samples + 1200*shade_points + 40*gi_children (rank 0's launch)"},
             "work_per_step": {k: v / args.steps for k, v in total.items()},
         }

@@ -58,6 +58,8 @@ def lib():
             "crt_selftest_rcp": (C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint32)]),
             "crt_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
             "crt_set_workspace_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
+            "crt_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+            "crt_get_kernel_times": (C.c_int, [C.c_void_p, P(C.c_double), P(C.c_uint64)]),
             "crt_set_audit": (C.c_int, [C.c_void_p, C.c_int]),
             "crt_audit_result": (C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint64)]),
             "crt_fb_alloc": (C.c_int, [C.c_void_p, C.c_size_t, P(C.c_void_p)]),
@@ -78,7 +80,8 @@ ABI_SYMBOLS = (
     "crt_create", "crt_destroy", "crt_last_error", "crt_cornell_scene", "crt_scene_upload", "crt_rng_init",
     "crt_rng_export", "crt_render", "crt_render_partial", "crt_render_shard", "crt_shard_tiles",
     "crt_shard_tiles_max", "crt_scatter_shards", "crt_stats_since_init", "crt_selftest_rcp", "crt_set_pipeline",
-    "crt_set_workspace_limit", "crt_set_audit", "crt_audit_result", "crt_fb_alloc", "crt_fb_free",
+    "crt_set_workspace_limit", "crt_set_audit", "crt_audit_result", "crt_set_timing",
+    "crt_get_kernel_times", "crt_fb_alloc", "crt_fb_free",
     "crt_fb_download", "crt_write_hdr", "crt_encode_hdr")
 
 
@@ -173,6 +176,18 @@ class Context:
 
     def set_workspace_limit(self, nbytes):
         self._check(lib().crt_set_workspace_limit(self._h, nbytes), "crt_set_workspace_limit")
+
+    KERNELS = ("trace", "filter", "resolve", "shade", "sum")
+
+    def set_timing(self, enabled):
+        self._check(lib().crt_set_timing(self._h, int(bool(enabled))), "crt_set_timing")
+
+    def kernel_times(self):
+        """{kernel: (milliseconds, launches)} of the wavefront pipeline since set_timing(True)."""
+        ms = (C.c_double * 5)()
+        n = (C.c_uint64 * 5)()
+        self._check(lib().crt_get_kernel_times(self._h, ms, n), "crt_get_kernel_times")
+        return {k: (ms[i], n[i]) for i, k in enumerate(self.KERNELS)}
 
     def set_audit(self, enabled):
         self._check(lib().crt_set_audit(self._h, int(bool(enabled))), "crt_set_audit")

@@ -335,6 +335,26 @@ int crt_set_pipeline(crt_ctx* ctx, int pipeline) {
     return CRT_OK;
 }
 
+int crt_set_timing(crt_ctx* ctx, int enabled) {
+    if (!ctx) return CRT_ERR_INVALID;
+    ctx->wf.timing = enabled != 0;
+    for (uint32_t k = 0; k < crt::WF_KERNEL_COUNT; ++k) {
+        ctx->wf.kernel_ms[k] = 0.0;
+        ctx->wf.kernel_launches[k] = 0;
+    }
+    return CRT_OK;
+}
+
+int crt_get_kernel_times(crt_ctx* ctx, double ms[5], uint64_t launches[5]) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!ms || !launches) return fail(ctx, CRT_ERR_INVALID, "NULL argument");
+    for (uint32_t k = 0; k < 5u; ++k) {
+        ms[k] = ctx->wf.kernel_ms[k];
+        launches[k] = ctx->wf.kernel_launches[k];
+    }
+    return CRT_OK;
+}
+
 int crt_set_audit(crt_ctx* ctx, int enabled) {
     if (!ctx) return CRT_ERR_INVALID;
     ctx->audit = enabled ? 1 : 0;

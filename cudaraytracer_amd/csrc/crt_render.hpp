@@ -33,6 +33,7 @@ struct RenderArgs {
 };
 
 // ---- wavefront pipeline (crt_wavefront.hip)
+enum WfKernel : uint32_t { WF_K_TRACE = 0, WF_K_FILTER, WF_K_RESOLVE, WF_K_SHADE, WF_K_SUM, WF_KERNEL_COUNT };
 // Device workspace of the multi-kernel pipeline; all planes are structure-of-arrays.
 struct WfWorkspace {
     uint32_t n_lp = 0;      // pixel slots (work units * 64) the planes are sized for
@@ -57,6 +58,11 @@ struct WfWorkspace {
     uint32_t jump_n[2] = {0, 0};    // step counts the tables were built for
     uint32_t* qcounts = nullptr;    // entries per filter wave
     size_t bytes = 0;
+    // optional per-kernel timing with HIP events on the launch stream (crt_set_timing)
+    bool timing = false;
+    void* timer = nullptr;   // event pool, owned by crt_wavefront.hip
+    double kernel_ms[WF_KERNEL_COUNT] = {0}; // accumulated since the last reset
+    uint64_t kernel_launches[WF_KERNEL_COUNT] = {0};
 };
 constexpr uint32_t WF_STATE_PLANES = 17, WF_FRAME_PLANES = 19, WF_WORK_PLANES = 21;
 enum WfCounter : uint32_t {

@@ -1465,6 +1465,56 @@ __global__ void __launch_bounds__(64) wf_sum_kernel(WfArgs w, uint32_t first) {
 
 int g_resident_cus[64] = {0};
 
+// Pairs of HIP events around kernel launches; read back once the stream has been synchronised.
+struct EventTimer {
+    struct Span {
+        hipEvent_t a, b;
+        uint32_t kernel;
+    };
+    std::vector<Span> pool;
+    size_t used = 0;
+    Span* begin(uint32_t kernel, hipStream_t stream) {
+        if (used == pool.size()) {
+            Span s;
+            if (hipEventCreate(&s.a) != hipSuccess) return nullptr;
+            if (hipEventCreate(&s.b) != hipSuccess) {
+                (void)hipEventDestroy(s.a);
+                return nullptr;
+            }
+            pool.push_back(s);
+        }
+        Span* s = &pool[used++];
+        s->kernel = kernel;
+        (void)hipEventRecord(s->a, stream);
+        return s;
+    }
+    static void end(Span* s, hipStream_t stream) {
+        if (s) (void)hipEventRecord(s->b, stream);
+    }
+    void collect(WfWorkspace& ws) { // the stream is idle
+        for (size_t i = 0; i < used; ++i) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, pool[i].a, pool[i].b) == hipSuccess) {
+                ws.kernel_ms[pool[i].kernel] += ms;
+                ws.kernel_launches[pool[i].kernel] += 1;
+            }
+        }
+        used = 0;
+    }
+    ~EventTimer() {
+        for (auto& s : pool) {
+            (void)hipEventDestroy(s.a);
+            (void)hipEventDestroy(s.b);
+        }
+    }
+};
+#define WF_TIMED(kernel_id, launch_stmt)                                                    \
+    do {                                                                                    \
+        EventTimer::Span* span_ = timer ? timer->begin(kernel_id, stream) : nullptr;        \
+        launch_stmt;                                                                        \
+        EventTimer::end(span_, stream);                                                     \
+    } while (0)
+
 // Table for rng_jump: images of every nibble value of every state word under `nsteps` XORWOW steps.
 void build_jump_table(uint32_t nsteps, uint32_t* tab) {
     for (uint32_t pos = 0; pos < 40u; ++pos) {
@@ -1509,8 +1559,11 @@ void wavefront_release(WfWorkspace& ws) {
     (void)hipFree(ws.shadow_cnt);
     (void)hipFree(ws.queue);
     (void)hipFree(ws.jump_dev);
+    delete static_cast<EventTimer*>(ws.timer);
     (void)hipFree(ws.qcounts);
+    const bool timing = ws.timing;
     ws = WfWorkspace();
+    ws.timing = timing;
 }
 
 hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n_lights, size_t budget_bytes) {
@@ -1588,6 +1641,8 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
 hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow) {
     *overflow = false;
     if (args.n_units == 0) return hipSuccess;
+    if (ws.timing && !ws.timer) ws.timer = new EventTimer();
+    EventTimer* timer = ws.timing ? static_cast<EventTimer*>(ws.timer) : nullptr;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -1657,8 +1712,8 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     for (;;) {
         e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_ERROR * sizeof(uint32_t), stream); // the error word is sticky
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(wf_trace_kernel, dim3((args.n_units + kTraceWaves - 1u) / kTraceWaves), dim3(64 * kTraceWaves), 0,
-                           stream, w, first);
+        WF_TIMED(WF_K_TRACE, hipLaunchKernelGGL(wf_trace_kernel, dim3((args.n_units + kTraceWaves - 1u) / kTraceWaves),
+                                                dim3(64 * kTraceWaves), 0, stream, w, first));
         e = hipMemcpyAsync(ws.ctrs_host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(stream);
@@ -1673,13 +1728,13 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
             const uint32_t b1 = n_work - b0 > batch ? b0 + batch : n_work;
             const uint32_t groups = (b1 - b0 + 63u) / 64u;
             const uint32_t fgrid = groups < fwaves ? groups : fwaves;
-            hipLaunchKernelGGL(wf_filter_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
+            WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1));
             if (args.audit) hipLaunchKernelGGL(wf_audit_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
-            hipLaunchKernelGGL(wf_resolve_kernel, dim3(fgrid * kResolveSplit), dim3(64), 0, stream, w);
+            WF_TIMED(WF_K_RESOLVE, hipLaunchKernelGGL(wf_resolve_kernel, dim3(fgrid * kResolveSplit), dim3(64), 0, stream, w));
         }
         if (n_work != 0u)
-            hipLaunchKernelGGL(wf_shade_kernel, dim3((n_work + 63u) / 64u), dim3(64), 0, stream, w, 0u, n_work);
-        hipLaunchKernelGGL(wf_sum_kernel, dim3(args.n_units), dim3(64), 0, stream, w, first);
+            WF_TIMED(WF_K_SHADE, hipLaunchKernelGGL(wf_shade_kernel, dim3((n_work + 63u) / 64u), dim3(64), 0, stream, w, 0u, n_work));
+        WF_TIMED(WF_K_SUM, hipLaunchKernelGGL(wf_sum_kernel, dim3(args.n_units), dim3(64), 0, stream, w, first));
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         first = 0u;
@@ -1691,6 +1746,7 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return e;
     if (ws.ctrs_host[WF_CTR_ERROR] != 0u) *overflow = true;
+    if (timer) timer->collect(ws);
     return hipSuccess;
 }
 

@@ -221,6 +221,13 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out);
 #define CRT_PIPELINE_PERSISTENT 1
 #define CRT_PIPELINE_WAVEFRONT 2
 int crt_set_pipeline(crt_ctx* ctx, int pipeline);
+/* Per-kernel GPU time of the wavefront pipeline, measured with HIP events on the launch stream.
+ * crt_set_timing(ctx, 1) starts (and zeroes) the accumulation, crt_get_kernel_times returns
+ * milliseconds and launch counts in the order trace, filter, resolve, shade, sum.  A workspace
+ * reallocation (new image size) keeps the setting but restarts the totals.  Measurement only; the
+ * reference prints one wall-clock "Render time" (main.cu:712-716). */
+int crt_set_timing(crt_ctx* ctx, int enabled);
+int crt_get_kernel_times(crt_ctx* ctx, double ms[5], uint64_t launches[5]);
 /* Test instrument of the wavefront pipeline.  Its filter kernel decides most shadow rays ("free" or
  * "blocked by an opaque primitive") with conservative tests and sends the rest to the exact test.
  * With the audit enabled every decided ray is also put through the exact test
