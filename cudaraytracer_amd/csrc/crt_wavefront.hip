@@ -937,7 +937,6 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
                     if (h.idx < 0) {
                         // final_color += attenuation * Color::black() (main.cu:149-151)
                         const V4 c = cur_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
-                        w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_ADD;
                         w.contrib[(size_t)cnt * n_lp + lp] = make_float4(c.x, c.y, c.z, c.w);
                         ++cnt;
                     } else {
@@ -1003,7 +1002,6 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
             if (emit) {
                 const uint32_t wi = my_wi;
                 const uint32_t slot_k = cnt;
-                w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_ADD;
                 ++cnt;
                 ++cnt_shade;
                 if (wi < w.cap_work) {
@@ -1711,6 +1709,9 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     if (e != hipSuccess) return e;
     for (;;) {
         e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_ERROR * sizeof(uint32_t), stream); // the error word is sticky
+        if (e != hipSuccess) return e;
+        // slot tags default to TAG_ADD (0): the trace kernel stores only the rare end-of-call / end-of-pixel marks
+        e = hipMemsetAsync(ws.tags, 0, (size_t)ws.quota * ws.n_lp, stream);
         if (e != hipSuccess) return e;
         WF_TIMED(WF_K_TRACE, hipLaunchKernelGGL(wf_trace_kernel, dim3((args.n_units + kTraceWaves - 1u) / kTraceWaves),
                                                 dim3(64 * kTraceWaves), 0, stream, w, first));
