@@ -41,7 +41,7 @@ namespace {
 enum : uint32_t { TAG_ADD = 0, TAG_END_CALL = 1, TAG_END_PIXEL = 2 };
 constexpr uint32_t kWorkChunk = 256;         // shade-record indices a trace wave reserves at a time
 constexpr uint32_t kMaxFilterWaves = 16384;   // upper bound of the filter kernel's grid
-constexpr uint32_t kResolveSplit = 8;         // resolve waves per filter wave's queue region
+constexpr uint32_t kResolveSplit = 8;        // resolve waves per filter wave's queue region
 constexpr uint32_t kNoRecord = 0xffffffffu;  // primitive index of an unused record slot
 
 // state planes
@@ -282,6 +282,8 @@ DI V3 sample_offset(const LightF& lf, V3 Bp0, V3 Bp1, float u, float v) {
     }
     return D;
 }
+// Quotient for the conservative tests only (1 ulp reciprocal estimate, no correction steps).
+DI float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 DI float fdot(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
 
 // For a parallelogram light D = Bp + e01 u + e03 v is affine in the two draws, so every quantity the
@@ -339,7 +341,7 @@ DI SphSlot make_sph_slot(V3 P, V3 center, float r2, V3 Bp, const LightF& lf, con
     const bool outside = c0 > 5e-4f && cm * cm > 1.61e-3f * e0 && e0 < 1e12f; // further than 0.02 from the surface
     const bool c_pos = c0 > 1e-3f * e0 && c0 > 1e-30f && e0 < 1e12f;
     s.M2 = outside ? __builtin_fmaf(1e-4f, a_max, s.M) : __builtin_inff();
-    s.kb = c_pos ? __builtin_sqrtf(1e-6f * (a_max * e0)) * 1.001f : __builtin_inff();
+    s.kb = c_pos ? __builtin_amdgcn_sqrtf(1e-6f * (a_max * e0)) * 1.001f : __builtin_inff();
     s.kc = c0 * 1.0011f;
     return s;
 }
@@ -411,12 +413,12 @@ DI QuadParSlot make_quad_par_slot(V3 P, V3 v0, V3 nor, float sp_min2, float n2, 
     const float sd = sP * dnq;
     q.behind = sd > 0.0f && offp;
     const float inf = __builtin_inff();
-    q.t_lift = __builtin_fminf(2.5e-5f * dn2 / sP2, dn2 / (4e-6f * n2));
+    q.t_lift = __builtin_fminf(fdiv(2.5e-5f * dn2, sP2) * 0.9999f, fdiv(dn2, 4e-6f * n2) * 0.9999f);
     const float e = __builtin_fabsf(sP) - ad * 1.000004f;
-    q.t_beyond = (!(sd > 0.0f) && offp && e > 0.0f) ? 1.004004e-4f * dn2 / (e * e) * 1.00001f : inf;
-    q.t_steep = dn2 / (1e-4f * n2) * 0.99999f;
-    q.t_between = (sd < 0.0f && offp && __builtin_fabsf(sP) < 0.999f * ad) ? 1.21e-4f * dn2 / sP2 * 1.00001f : inf;
-    const float sc_ = -sP / dnq; // ray parameter of the plane
+    q.t_beyond = (!(sd > 0.0f) && offp && e > 0.0f) ? fdiv(1.004004e-4f * dn2, e * e) * 1.0001f : inf;
+    q.t_steep = fdiv(dn2, 1e-4f * n2) * 0.9999f;
+    q.t_between = (sd < 0.0f && offp && __builtin_fabsf(sP) < 0.999f * ad) ? fdiv(1.21e-4f * dn2, sP2) * 1.0001f : inf;
+    const float sc_ = -fdiv(sP, dnq); // ray parameter of the plane (box margins cover the 1e-7 error)
     const float Pk[3] = {P.x, P.y, P.z}, Bk[3] = {Bp.x, Bp.y, Bp.z}, e1[3] = {lf.e01.x, lf.e01.y, lf.e01.z},
                 e3[3] = {lf.e03.x, lf.e03.y, lf.e03.z}, mk[3] = {mid.x, mid.y, mid.z};
 #pragma unroll
@@ -669,10 +671,10 @@ DI uint32_t record_light_class(ScenePtr sc, uint32_t li, const LightF& lf, V3 P)
     const bool rec_ok = pl * pl > 1.0001e-6f * nl2 && a_max < 1e12f && nl2 > 1e-30f && nl2 < 1e30f;
     if (!rec_ok) return 0u;
     // lower bound of a: exact minimum over the square for a rectangle, else the squared distance to the light's plane
-    float a_min = (pl * pl) / nl2;
+    float a_min = fdiv(pl * pl, nl2);
     if (lf.g12x2 * lf.g12x2 <= 1e-12f * (lf.g11 * lf.g22)) {
-        const float us = __builtin_fminf(__builtin_fmaxf(-0.5f * pa.h1x2 / lf.g11, 0.0f), 1.0f);
-        const float vs = __builtin_fminf(__builtin_fmaxf(-0.5f * pa.h2x2 / lf.g22, 0.0f), 1.0f);
+        const float us = __builtin_fminf(__builtin_fmaxf(fdiv(-0.5f * pa.h1x2, lf.g11), 0.0f), 1.0f);
+        const float vs = __builtin_fminf(__builtin_fmaxf(fdiv(-0.5f * pa.h2x2, lf.g22), 0.0f), 1.0f);
         const float am = __builtin_fmaf(__builtin_fmaf(lf.g11, us, pa.h1x2), us, __builtin_fmaf(__builtin_fmaf(lf.g22, vs, pa.h2x2), vs, pa.h0));
         a_min = __builtin_fmaxf(a_min, am);
     }
