@@ -68,6 +68,7 @@ constexpr uint32_t WF_STATE_PLANES = 17, WF_FRAME_PLANES = 19, WF_WORK_PLANES = 
 enum WfCounter : uint32_t {
     WF_CTR_WORK = 0,    // shade records emitted this round
     WF_CTR_ACTIVE = 1,  // pixels not finished after this round
+    WF_CTR_QOVERFLOW = 3, // a filter wave ran out of queue space in an optimistically sized launch (cleared per round)
     WF_CTR_ERROR = 5,   // non-zero: a capacity was exceeded (results invalid)
     WF_CTR_COUNT = 16,
 };

@@ -41,6 +41,7 @@ namespace {
 enum : uint32_t { TAG_ADD = 0, TAG_END_CALL = 1, TAG_END_PIXEL = 2 };
 constexpr uint32_t kWorkChunk = 256;         // shade-record indices a trace wave reserves at a time
 constexpr uint32_t kMaxFilterWaves = 16384;   // upper bound of the filter kernel's grid
+constexpr uint32_t kOptimism = 8;            // first filter attempt: records per launch relative to the worst-case bound
 constexpr uint32_t kResolveSplit = 8;        // resolve waves per filter wave's queue region
 constexpr uint32_t kNoRecord = 0xffffffffu;  // primitive index of an unused record slot
 
@@ -130,7 +131,7 @@ DI void stage_flush(const WfArgs& w, uint32_t (*stg)[kStageCap], Stage& st, uint
             w.queue[(size_t)w.qcap + idx] = stg[1][pos];
             w.queue[2 * (size_t)w.qcap + idx] = stg[2][pos];
         } else {
-            w.ctrs[WF_CTR_ERROR] = 2u;
+            w.ctrs[WF_CTR_QOVERFLOW] = 1u;
         }
     }
     st.head = (st.head + n) & (kStageCap - 1u);
@@ -1602,6 +1603,7 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     // at most 2^30 rays (12.9 GB), less when all records of a round cast fewer
     uint64_t qwant = (uint64_t)cap_work * (args.max_shadow_rays ? args.max_shadow_rays : 1u) + 64ull * kMaxFilterWaves;
     if (qwant > (1ull << 30)) qwant = 1ull << 30;
+    if (qwant > budget_bytes / 36u) qwant = budget_bytes / 36u; // at most a third of the budget (12 B per ray)
     if (qwant < (1ull << 20)) qwant = 1ull << 20;
     const uint32_t qcap = (uint32_t)qwant;
     size_t total = 0;
@@ -1727,13 +1729,36 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
             *overflow = true;
             return hipSuccess;
         }
-        for (uint32_t b0 = 0; b0 < n_work; b0 += batch) {
-            const uint32_t b1 = n_work - b0 > batch ? b0 + batch : n_work;
-            const uint32_t groups = (b1 - b0 + 63u) / 64u;
-            const uint32_t fgrid = groups < fwaves ? groups : fwaves;
-            WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1));
-            if (args.audit) hipLaunchKernelGGL(wf_audit_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
-            WF_TIMED(WF_K_RESOLVE, hipLaunchKernelGGL(wf_resolve_kernel, dim3(fgrid * kResolveSplit), dim3(64), 0, stream, w));
+        // Filter and resolve.  A queue region sized for the worst case (every shadow ray undecided) allows
+        // `batch` records per launch; since normally a few per cent are undecided, the first attempt gives
+        // every wave kOptimism times as many records.  If a region overflows, the kernels have dropped rays
+        // (never written out of bounds) and the round's visibility is redone with worst-case launches: the
+        // filter kernel rewrites every record's count from scratch.
+        for (uint32_t attempt = 0; attempt < 2u && n_work != 0u; ++attempt) {
+            const uint64_t step64 = attempt == 0u ? (uint64_t)batch * kOptimism : batch;
+            const uint32_t step = step64 > 0x40000000ull ? 0x40000000u : (uint32_t)step64;
+            for (uint32_t b0 = 0; b0 < n_work; b0 += step) {
+                const uint32_t b1 = n_work - b0 > step ? b0 + step : n_work;
+                const uint32_t groups = (b1 - b0 + 63u) / 64u;
+                const uint32_t fgrid = groups < fwaves ? groups : fwaves;
+                WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1));
+                if (args.audit && attempt == 1u) hipLaunchKernelGGL(wf_audit_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
+                WF_TIMED(WF_K_RESOLVE,
+                         hipLaunchKernelGGL(wf_resolve_kernel, dim3(fgrid * kResolveSplit), dim3(64), 0, stream, w));
+            }
+            if (attempt == 1u) break;
+            e = hipMemcpyAsync(ws.ctrs_host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return e;
+            if (ws.ctrs_host[WF_CTR_QOVERFLOW] == 0u) {
+                if (args.audit) { // the audit reads records only, so it can follow the successful attempt
+                    const uint32_t groups = (n_work + 63u) / 64u;
+                    hipLaunchKernelGGL(wf_audit_kernel, dim3(groups < fwaves ? groups : fwaves), dim3(64), 0, stream, w, 0u, n_work);
+                }
+                break;
+            }
+            e = hipMemsetAsync(ws.ctrs + WF_CTR_QOVERFLOW, 0, sizeof(uint32_t), stream);
+            if (e != hipSuccess) return e;
         }
         if (n_work != 0u)
             WF_TIMED(WF_K_SHADE, hipLaunchKernelGGL(wf_shade_kernel, dim3((n_work + 63u) / 64u), dim3(64), 0, stream, w, 0u, n_work));

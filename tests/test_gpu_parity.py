@@ -313,3 +313,35 @@ def test_filter_decisions_agree_with_the_exact_test(kind):
             assert checked > 0
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_wavefront_redoes_a_round_when_the_ray_queue_overflows(oracle):
+    """A glass sphere under the light leaves nearly every shadow ray undecided.  With a 1 MiB workspace
+    limit the undecided-ray queue holds 2^20 rays, the optimistic first filter launch overflows it and the
+    round is redone with worst-case launches; the image must not change."""
+    from cudaraytracer_amd import abi
+
+    def scene(mod):
+        base = crt.cornell_box(50)
+        geo = [abi.crt_geometry.from_buffer_copy(bytes(g)) for g in base.geometry]
+        geo[1].center[0], geo[1].center[1], geo[1].center[2] = 0.0, 0.45, -1.0
+        geo[1].radius = 0.45
+        lights = [abi.crt_light.from_buffer_copy(bytes(base.lights[0]))]
+        cam = abi.crt_camera.from_buffer_copy(bytes(base.camera))
+        return mod.Scene(cam, geo, lights)
+
+    st = crt.make_settings(nx=64, ny=64, aa_iter=1, gl_iter=1, ind_rays=12, shadowSamples=50)
+    ctx = _wavefront_ctx()
+    try:
+        ctx.set_workspace_limit(1 << 20)
+        ctx.set_timing(True)
+        fb, state = _gpu_render(ctx, scene(crt), st, 3)
+        times = ctx.kernel_times()
+        rounds, filter_launches = times["trace"][1], times["filter"][1]
+        assert filter_launches > rounds, "the overflow path was not exercised"
+        ref, _, ref_state = oracle.render(scene(oracle), st, 3, want_state=True)
+        assert np.array_equal(state, ref_state)
+        assert np.array_equal(fb, ref)
+    finally:
+        ctx.close()
