@@ -213,23 +213,25 @@ DI void rng_unstep(Rng& s) {
 }
 
 // n steps at once.  The five xorshift words evolve linearly over GF(2), so the state after n steps is
-// the XOR of per-nibble table entries: tab[w][(word * 8 + nibble) * 16 + value] is word w of the image of
-// that nibble value (40 nibbles, 640 entries per plane, built on the host by stepping basis states);
-// the Weyl word just advances by n * 362437.
-constexpr uint32_t kJumpPlane = 640, kJumpWords = 5 * kJumpPlane;
+// the XOR of per-nibble table entries: entry e = (word * 8 + nibble) * 16 + value holds the image of that
+// nibble value, words 0..3 at tab[4e .. 4e+3] (one 16-byte read) and word 4 at tab[4 * 640 + e]; the
+// table is built on the host by stepping basis states.  The Weyl word just advances by n * 362437.
+constexpr uint32_t kJumpEntries = 640, kJumpWords = 5 * kJumpEntries;
 DI void rng_jump(Rng& s, const uint32_t* tab, uint32_t weyl_step) {
     const uint32_t in[5] = {s.v0, s.v1, s.v2, s.v3, s.v4};
     uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+    const uint4* tab4 = reinterpret_cast<const uint4*>(tab);
 #pragma unroll
     for (int wd = 0; wd < 5; ++wd) {
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) {
             const uint32_t idx = (uint32_t)(wd * 8 + nb) * 16u + ((in[wd] >> (4 * nb)) & 15u);
-            o0 ^= tab[idx];
-            o1 ^= tab[kJumpPlane + idx];
-            o2 ^= tab[2 * kJumpPlane + idx];
-            o3 ^= tab[3 * kJumpPlane + idx];
-            o4 ^= tab[4 * kJumpPlane + idx];
+            const uint4 q = tab4[idx];
+            o0 ^= q.x;
+            o1 ^= q.y;
+            o2 ^= q.z;
+            o3 ^= q.w;
+            o4 ^= tab[4u * kJumpEntries + idx];
         }
     }
     s.v0 = o0;

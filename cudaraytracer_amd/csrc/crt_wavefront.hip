@@ -739,7 +739,7 @@ constexpr uint32_t kTraceWaves = 4; // waves per trace workgroup (they share the
 __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w, uint32_t first) {
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
-    __shared__ uint32_t s_jump[2][kJumpWords];
+    __shared__ __attribute__((aligned(16))) uint32_t s_jump[2][kJumpWords];
     for (uint32_t k = threadIdx.x; k < 2u * kJumpWords; k += 64u * kTraceWaves)
         s_jump[k / kJumpWords][k % kJumpWords] = w.jump_tabs[k];
     __syncthreads();
@@ -1538,7 +1538,9 @@ void build_jump_table(uint32_t nsteps, uint32_t* tab) {
                 uint32_t x = 0;
                 for (uint32_t bit = 0; bit < 4u; ++bit)
                     if ((val >> bit) & 1u) x ^= basis[bit][wd];
-                tab[(size_t)wd * kJumpPlane + pos * 16u + val] = x;
+                const uint32_t e = pos * 16u + val;
+                if (wd < 4) tab[4u * e + (uint32_t)wd] = x;
+                else tab[4u * kJumpEntries + e] = x;
             }
     }
 }
