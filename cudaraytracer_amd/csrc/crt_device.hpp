@@ -581,7 +581,19 @@ DI bool covered_through_glass(ScenePtr sc, const DevLight CRT_CONST* L, V3 o, V3
         d = rdir;
         ++i;
         if (!(i < 10u)) return true; // loop ends with hit.isHit still set
-        h = closest_hit(sc, o, d, 0.0f);
+        // Inside a glass sphere the ray leaves the ball within 2r: only primitives that reach into the
+        // ball can be hit first (DevScene::interior_*).  Robustly inside: |o - C|^2 < r^2 (1 - 1e-5).
+        uint64_t candidates = ~0ull;
+        {
+            const DevGeomHot* g = (const DevGeomHot*)&sc->hot[h.idx];
+            if (g->kind == CRT_GEOM_SPHERE) {
+                const V3 L = o - V3{g->o[0], g->o[1], g->o[2]};
+                const float r2 = g->n[0];
+                if (len_sq(L) < r2 - 1e-5f * r2)
+                    candidates = ((uint64_t)((const uint32_t*)sc->interior_hi)[h.idx] << 32) | ((const uint32_t*)sc->interior_lo)[h.idx];
+            }
+        }
+        h = closest_hit_masked(sc, o, d, 0.0f, candidates);
         if (h.idx < 0) return false;
         if (h.mat_type != CRT_MAT_REFRACTIVE) return true;
     }

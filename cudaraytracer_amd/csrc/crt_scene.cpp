@@ -323,6 +323,37 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
         }
         for (int k = 0; k < 7; ++k) b.pad2[k] = 0.0f;
     }
+    for (uint32_t g = 0; g < CRT_MAX_GEOMETRY; ++g) {
+        out->interior_lo[g] = out->interior_hi[g] = 0xffffffffu;
+        if (g >= in->n_geometry || in->geometry[g].kind != CRT_GEOM_SPHERE || !(rabs > 0.0) || !(rabs < 1e6)) continue;
+        const crt_geometry& sg = in->geometry[g];
+        const double reach = fabs((double)sg.radius) + 1e-3 * rabs + 0.02;
+        uint64_t mask = 0;
+        for (uint32_t j = 0; j < in->n_geometry; ++j) {
+            const crt_geometry& o = in->geometry[j];
+            double d2 = 0.0; // squared distance from the sphere's centre to primitive j (to its bounding box for a quad)
+            if (o.kind == CRT_GEOM_SPHERE) {
+                double c2 = 0.0;
+                for (int k = 0; k < 3; ++k) c2 += ((double)o.center[k] - sg.center[k]) * ((double)o.center[k] - sg.center[k]);
+                const double gap = sqrt(c2) - fabs((double)o.radius);
+                d2 = gap > 0.0 ? gap * gap : 0.0;
+            } else {
+                for (int k = 0; k < 3; ++k) {
+                    double lo = INFINITY, hi = -INFINITY;
+                    for (int v = 0; v < 4; ++v) {
+                        lo = fmin(lo, (double)o.v[v].pos[k]);
+                        hi = fmax(hi, (double)o.v[v].pos[k]);
+                    }
+                    const double c = sg.center[k];
+                    const double gap = c < lo ? lo - c : (c > hi ? c - hi : 0.0);
+                    d2 += gap * gap;
+                }
+            }
+            if (j == g || !(d2 > reach * reach)) mask |= 1ull << j;
+        }
+        out->interior_lo[g] = (uint32_t)mask;
+        out->interior_hi[g] = (uint32_t)(mask >> 32);
+    }
     const double dmax = 3.5 * rabs; // > 2*sqrt(3)*rabs: no two scene points are further apart
     for (uint32_t l = 0; l < CRT_MAX_LIGHTS; ++l)
         for (uint32_t i = 0; i < CRT_MAX_GEOMETRY; ++i) {

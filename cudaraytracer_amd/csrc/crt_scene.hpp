@@ -119,6 +119,10 @@ struct alignas(64) DevScene {
     // s * cull_side[l][g] > cull_thr[l][g] (the whole light lies on that side of the quad's plane,
     // further than the 0.01 the ray overshoots, and P is on the same side or on the plane itself).
     // cull_thr = +inf where no such statement holds (spheres, quads the light straddles or touches).
+    // For a sphere g: the primitives that come within its ball (itself included).  A ray that starts
+    // inside the ball leaves it after at most 2r, so nothing outside this set can be its closest hit.
+    // All ones for quads.
+    uint32_t interior_lo[CRT_MAX_GEOMETRY], interior_hi[CRT_MAX_GEOMETRY];
     // 1 when quad g is parallel to the plane of area light l (nor.D is then the same for every sample)
     uint32_t quad_par[CRT_MAX_LIGHTS][CRT_MAX_GEOMETRY];
     float cull_side[CRT_MAX_LIGHTS][CRT_MAX_GEOMETRY];
