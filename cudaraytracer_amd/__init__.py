@@ -67,6 +67,8 @@ def lib():
             "crt_fb_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
             "crt_write_hdr": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
             "crt_encode_hdr": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+            "crt_to_rgba8": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+            "crt_write_ppm": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)  # AttributeError here = the library does not export the declared ABI
@@ -82,7 +84,7 @@ ABI_SYMBOLS = (
     "crt_shard_tiles_max", "crt_scatter_shards", "crt_stats_since_init", "crt_selftest_rcp", "crt_set_pipeline",
     "crt_set_workspace_limit", "crt_set_audit", "crt_audit_result", "crt_set_timing",
     "crt_get_kernel_times", "crt_fb_alloc", "crt_fb_free",
-    "crt_fb_download", "crt_write_hdr", "crt_encode_hdr")
+    "crt_fb_download", "crt_write_hdr", "crt_encode_hdr", "crt_to_rgba8", "crt_write_ppm")
 
 
 class Scene:
@@ -262,3 +264,23 @@ def write_hdr(path, image):
     rc = lib().crt_write_hdr(str(path).encode(), w, h, comp, img.ctypes.data)
     if rc != abi.CRT_OK:
         raise CrtError(rc, "crt_write_hdr")
+
+
+def to_rgba8(image):
+    """uint8 preview of a float image: (uint8)clamp(c * 255, 0, 255) per value (main.cu:816-818)."""
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    out = np.empty(img.shape, dtype=np.uint8)
+    rc = lib().crt_to_rgba8(img.ctypes.data, img.size, out.ctypes.data)
+    if rc != abi.CRT_OK:
+        raise CrtError(rc, "crt_to_rgba8")
+    return out
+
+
+def write_ppm(path, rgba8):
+    img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    h, w, comp = img.shape
+    if comp != 4:
+        raise ValueError("write_ppm expects an RGBA8 image [h, w, 4]")
+    rc = lib().crt_write_ppm(str(path).encode(), w, h, img.ctypes.data)
+    if rc != abi.CRT_OK:
+        raise CrtError(rc, "crt_write_ppm")

@@ -119,3 +119,28 @@ extern "C" int crt_write_hdr(const char* path, int w, int h, int comp, const flo
     int rc = fclose(f);
     return (n == bytes.size() && rc == 0) ? CRT_OK : CRT_ERR_IO;
 }
+
+// 8-bit preview (main.cu:816-818): truncating conversion of clamp(c * 255, 0, 255).
+extern "C" int crt_to_rgba8(const float* in, size_t n, uint8_t* out) {
+    if ((!in || !out) && n != 0) return CRT_ERR_INVALID;
+    for (size_t i = 0; i < n; ++i) {
+        const float v = in[i] * 255.0f;
+        out[i] = v >= 255.0f ? (uint8_t)255 : (v > 0.0f ? (uint8_t)v : (uint8_t)0); // NaN -> 0
+    }
+    return CRT_OK;
+}
+
+extern "C" int crt_write_ppm(const char* path, int w, int h, const uint8_t* rgba8) {
+    if (!path || !rgba8 || w <= 0 || h <= 0) return CRT_ERR_INVALID;
+    FILE* f = fopen(path, "wb");
+    if (!f) return CRT_ERR_IO;
+    bool ok = fprintf(f, "P6\n%d %d\n255\n", w, h) > 0;
+    std::vector<unsigned char> row((size_t)w * 3u);
+    for (int j = 0; j < h && ok; ++j) {
+        for (int i = 0; i < w; ++i)
+            for (int c = 0; c < 3; ++c) row[(size_t)i * 3u + c] = rgba8[((size_t)j * w + i) * 4u + c];
+        ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+    }
+    const int rc = fclose(f);
+    return (ok && rc == 0) ? CRT_OK : CRT_ERR_IO;
+}

@@ -5,7 +5,7 @@
 //
 //   crt_main [--nx N] [--ny N] [--aa_iter N] [--ref_iter N] [--gl_iter N] [--ind_rays N]
 //            [--shadowSamples N] [--tx N] [--ty N] [--blocksPerDraw N] [--progressive]
-//            [--seed S] [--device D] [--out file.hdr]
+//            [--seed S] [--device D] [--out file.hdr] [--preview file.ppm]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
     unsigned long long seed = static_cast<unsigned long long>(std::time(nullptr)); // main.cu:952
     int device = 0;
     std::string out = "file.hdr";
+    std::string preview; // 8-bit view of the frame, what the reference shows in its window (main.cu:812-818)
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char* {
@@ -51,6 +52,7 @@ int main(int argc, char** argv) {
         else if (a == "--seed") seed = std::strtoull(next(), nullptr, 10);
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--out") out = next();
+        else if (a == "--preview") preview = next();
         else {
             std::fprintf(stderr, "unknown option %s\n", a.c_str());
             return 2;
@@ -77,6 +79,15 @@ int main(int argc, char** argv) {
             return 1;
         }
         std::printf("\nImage saved as '%s'.\n", out.c_str());
+        if (!preview.empty()) {
+            std::vector<uint8_t> px(fb.size());
+            if (crt_to_rgba8(fb.data(), fb.size(), px.data()) != CRT_OK ||
+                crt_write_ppm(preview.c_str(), static_cast<int>(s.nx), static_cast<int>(s.ny), px.data()) != CRT_OK) {
+                std::fprintf(stderr, "could not write %s\n", preview.c_str());
+                return 1;
+            }
+            std::printf("Preview saved as '%s'.\n", preview.c_str());
+        }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 99; // the reference exits with 99 on a device error (main.cu:901)

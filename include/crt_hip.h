@@ -263,6 +263,14 @@ int crt_write_hdr(const char* path, int w, int h, int comp, const float* data);
  * Pass out=NULL to query the size bound. */
 long crt_encode_hdr(int w, int h, int comp, const float* data, unsigned char* out, size_t cap);
 
+/* 8-bit preview of a float image, the conversion the reference applies before handing the frame to its
+ * SFML texture: out[i] = (uint8_t)clamp(in[i] * 255.0f, 0.f, 255.f) for every channel value
+ * (main.cu:816-818); NaN maps to 0.  Host code, n values in and out. */
+int crt_to_rgba8(const float* in, size_t n, uint8_t* out);
+/* Writes the RGB part of an RGBA8 image as a binary PPM (P6), rows top to bottom -- the headless
+ * stand-in for the reference's preview window (main.cu:812-853). */
+int crt_write_ppm(const char* path, int w, int h, const uint8_t* rgba8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,3 +54,24 @@ def test_runs_literals_and_long_rows_roundtrip():
     assert np.abs(rgbe_to_float(rgbe) - img).max() < 1 / 128
     # a constant plane of 300 bytes needs three run packets (127 + 127 + 46)
     assert bytes([128 + 127, rgbe[0, 0, 2], 128 + 127, rgbe[0, 0, 2], 128 + 46, rgbe[0, 0, 2]]) in raw
+
+
+def test_rgba8_preview_matches_the_reference_conversion(tmp_path):
+    """main.cu:816-818: static_cast<uint8_t>(std::clamp(c * 255.0f, 0.f, 255.f)), then a PPM of the RGB part."""
+    import cudaraytracer_amd as crt
+    rng = np.random.default_rng(5)
+    img = rng.uniform(-0.2, 1.3, size=(9, 13, 4)).astype(np.float32)
+    img[0, 0] = [0.0, 1.0, 0.5, 254.999 / 255.0]
+    img[0, 1] = [np.nan, np.inf, -np.inf, 1e-9]
+    got = crt.to_rgba8(img)
+    with np.errstate(invalid="ignore"):
+        want = np.clip(img * np.float32(255.0), 0.0, 255.0)
+    want = np.where(np.isnan(want), 0.0, want).astype(np.uint8)  # truncation
+    assert np.array_equal(got, want)
+    assert list(got[0, 0]) == [0, 255, 127, 254]
+    path = tmp_path / "preview.ppm"
+    crt.write_ppm(path, got)
+    raw = path.read_bytes()
+    header = b"P6\n13 9\n255\n"
+    assert raw.startswith(header)
+    assert np.array_equal(np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(9, 13, 3), got[:, :, :3])
