@@ -102,7 +102,7 @@ crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
 int run_render(crt_ctx* ctx, const crt::RenderArgs& a, hipStream_t stream) {
     const bool can_wf = crt::wavefront_supports(a);
     if (ctx->pipeline == CRT_PIPELINE_WAVEFRONT && !can_wf)
-        return fail(ctx, CRT_ERR_UNSUPPORTED, "the wavefront pipeline needs aa_iter <= 1 (got %u)", a.aa_iter);
+        return fail(ctx, CRT_ERR_UNSUPPORTED, "the wavefront pipeline does not implement these settings");
     if (ctx->pipeline == CRT_PIPELINE_PERSISTENT || !can_wf) {
         HIP_TRY(ctx, crt::launch_render(a, stream));
         return CRT_OK;

@@ -50,7 +50,8 @@ struct WfWorkspace {
     uint8_t* tags = nullptr;        // [quota][n_lp]
     float* contrib = nullptr;       // [quota][n_lp] float4
     uint32_t* slot_count = nullptr; // [n_lp]
-    float* px_acc = nullptr;        // [2][n_lp] float4: colour of the running color() call, pixel accumulator
+    float* px_acc = nullptr;        // [3][n_lp] float4: colour of the running color() call, pixel accumulator, first corner of the running AA task
+    uint32_t* aa_verdict = nullptr; // [n_lp]: the sum kernel's verdict on a finished level >= 2 AA task
     uint32_t* work = nullptr;       // [WF_WORK_PLANES][cap_work]
     uint32_t* shadow_cnt = nullptr; // [n_lights][cap_work]
     uint32_t* queue = nullptr;      // [3][qcap]
@@ -64,7 +65,7 @@ struct WfWorkspace {
     double kernel_ms[WF_KERNEL_COUNT] = {0}; // accumulated since the last reset
     uint64_t kernel_launches[WF_KERNEL_COUNT] = {0};
 };
-constexpr uint32_t WF_STATE_PLANES = 17, WF_FRAME_PLANES = 19, WF_WORK_PLANES = 21;
+constexpr uint32_t WF_STATE_PLANES = 49, WF_FRAME_PLANES = 19, WF_WORK_PLANES = 21;
 enum WfCounter : uint32_t {
     WF_CTR_WORK = 0,    // shade records emitted this round
     WF_CTR_ACTIVE = 1,  // pixels not finished after this round
@@ -72,7 +73,7 @@ enum WfCounter : uint32_t {
     WF_CTR_ERROR = 5,   // non-zero: a capacity was exceeded (results invalid)
     WF_CTR_COUNT = 16,
 };
-// True when the wavefront pipeline implements these settings (aa_iter <= 1: no colour-dependent control flow).
+// True when the wavefront pipeline implements these settings (all of them).
 bool wavefront_supports(const RenderArgs& args);
 // Frees / (re)allocates the workspace for this launch; returns hipSuccess or the allocation error.
 hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n_lights, size_t budget_bytes);

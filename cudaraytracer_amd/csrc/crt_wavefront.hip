@@ -38,7 +38,10 @@ namespace crt {
 
 namespace {
 
+// slot tags: type in bits 0..1; an end-of-call tag carries its AA task's level (bits 2..4) and corner (bits 5..6)
 enum : uint32_t { TAG_ADD = 0, TAG_END_CALL = 1, TAG_END_PIXEL = 2 };
+// verdict of the sum kernel on a finished level >= 2 AA task (main.cu:283-300)
+enum : uint32_t { AA_PENDING = 0, AA_ALL_EQUAL = 1, AA_SUBDIVIDE = 2 };
 constexpr uint32_t kWorkChunk = 256;         // shade-record indices a trace wave reserves at a time
 constexpr uint32_t kMaxFilterWaves = 16384;   // upper bound of the filter kernel's grid
 constexpr uint32_t kOptimism = 8;            // first filter attempt: records per launch relative to the worst-case bound
@@ -47,8 +50,11 @@ constexpr uint32_t kNoRecord = 0xffffffffu;  // primitive index of an unused rec
 
 // state planes
 enum : uint32_t {
-    ST_CTL = 0,   // bit0 done, bit1 color_active, bit2 cur_valid, bits 4..7 call, bits 8..11 nframes
+    ST_CTL = 0,   // bit0 done, bit1 color_active, bit2 cur_valid, bit3 task_active, bit4 waiting for the AA verdict,
+                  // bits 5..7 task level, bits 8..10 task corner, bits 12..15 AA stack fill, bits 16..19 nframes
     ST_CUR_O = 1, ST_CUR_D = 4, ST_CUR_ATT = 7, ST_CUR_REF = 11, ST_CUR_DEPTH = 12, ST_RAY_D = 13, ST_ON_STACK = 16,
+    ST_T_CX = 17, ST_T_CY = 18, // centre of the running AA task
+    ST_AA = 19,                 // AA task stack: 10 x {cx, cy, level} (aa_color, main.cu:235-242; aa_iter <= 4 bounds it)
 };
 // frame planes
 enum : uint32_t { FR_P = 0, FR_N = 3, FR_ATT = 6, FR_RNG = 10, FR_GEOM = 16, FR_REMAINING = 17, FR_CHILD_DEPTH = 18 };
@@ -65,6 +71,7 @@ struct WfArgs {
     float4* contrib;
     uint32_t* slot_count;
     float4* px_acc;
+    uint32_t* aa_verdict; // [n_lp]: AA_* | all-equal-so-far << 8
     uint32_t* work;
     uint32_t* shadow_cnt;
     const uint32_t* jump_tabs; // two rng_jump tables: [0] for jump_n[0] = draws per shaded point, [1] for jump_n[1] = 2 ind_rays
@@ -766,8 +773,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
         float aspect = height_world / width_world;
         ortho = sc->cam.ortho_scale * (aspect > 1.0f ? aspect : 1.0f);
     }
-    const uint32_t aa_iter = a.aa_iter;                // 0 or 1 here
-    const uint32_t n_calls = aa_iter == 0u ? 1u : 4u;  // color() calls per pixel (main.cu:254-268)
+    const uint32_t aa_iter = a.aa_iter > 4u ? 4u : a.aa_iter; // main.cu:233
     const float inv_ind = 1.0f / (float)a.ind_rays;    // main.cu:182
     // generator draws one diffuse hit consumes in LightList::calculateColor (AreaLight.hpp:342-343,495)
     uint32_t skip_draws = 0;
@@ -782,7 +788,9 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
     bool done = !pm.valid || (ctl & 1u);
     const bool live_at_entry = !done;
     bool color_active = (ctl >> 1) & 1u, cur_valid = (ctl >> 2) & 1u;
-    uint32_t call = (ctl >> 4) & 15u, nframes = (ctl >> 8) & 15u;
+    bool task_active = (ctl >> 3) & 1u, waiting = (ctl >> 4) & 1u;
+    uint32_t t_level = (ctl >> 5) & 7u, t_corner = (ctl >> 8) & 7u, aa_top = (ctl >> 12) & 15u, nframes = (ctl >> 16) & 15u;
+    float t_cx = 0.0f, t_cy = 0.0f;
     Rng rng = {0, 0, 0, 0, 0, 0};
     V3 cur_o = mk3(0, 0, 0), cur_d = mk3(0, 0, 0), ray_d = mk3(0.0f, 0.0f, -1.0f);
     V4 cur_att = V4{1, 1, 1, 1};
@@ -804,6 +812,8 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
             cur_depth = s[ST_CUR_DEPTH * n_lp];
             ray_d = mk3(u2f(s[(ST_RAY_D + 0) * n_lp]), u2f(s[(ST_RAY_D + 1) * n_lp]), u2f(s[(ST_RAY_D + 2) * n_lp]));
             on_stack = s[ST_ON_STACK * n_lp];
+            t_cx = u2f(s[ST_T_CX * n_lp]);
+            t_cy = u2f(s[ST_T_CY * n_lp]);
         }
     }
     // remap<float,true> (math_functions.hpp:31-45)
@@ -816,6 +826,34 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
         y_world = (denomy == 0.0f) ? (float)pm.j : 1.0f + ((-1.0f - 1.0f) / denomy) * ((float)pm.j - 0.0f);
     }
 
+    // aa_color's task list (main.cu:230-304) lives in the state planes; it starts with the whole pixel
+    uint32_t* aa_stack = w.state + (size_t)ST_AA * n_lp + lp; // entry e: planes 3e, 3e+1, 3e+2
+    if (first && live_at_entry) {
+        aa_stack[0 * n_lp] = f2u(x_world);
+        aa_stack[1 * n_lp] = f2u(y_world);
+        aa_stack[2 * n_lp] = aa_iter;
+        aa_top = 1;
+    }
+    if (waiting) {
+        // the sum kernel has compared the four corner colours of the level >= 2 task that ended last round
+        const uint32_t verdict = w.aa_verdict[lp] & 0xffu;
+        if (verdict == AA_SUBDIVIDE) { // main.cu:293-299: four tasks one level down, at the quarter points
+            float sx = pix_w, sy = pix_h;
+            for (uint32_t k = t_level; k < aa_iter; ++k) {
+                sx = sx * 0.5f;
+                sy = sy * 0.5f;
+            }
+            const float hx = sx * 0.5f, hy = sy * 0.5f;
+            for (uint32_t c = 0; c < 4u; ++c) {
+                const float ox = (c & 1u) ? 1.0f : -1.0f, oy = (c & 2u) ? 1.0f : -1.0f;
+                aa_stack[(3u * aa_top + 0u) * n_lp] = f2u(t_cx + ox * hx * 0.5f);
+                aa_stack[(3u * aa_top + 1u) * n_lp] = f2u(t_cy + oy * hy * 0.5f);
+                aa_stack[(3u * aa_top + 2u) * n_lp] = t_level - 1u;
+                ++aa_top;
+            }
+        }
+        waiting = false;
+    }
     uint32_t cnt = 0; // result slots filled this round
     uint32_t cnt_shade = 0, cnt_expand = 0;
     const uint32_t quota = w.quota;
@@ -825,7 +863,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
     bool have_chunk = false;
 
     for (;;) {
-        const bool go = !done && cnt < quota;
+        const bool go = !done && !waiting && cnt < quota;
         if (!__any(go)) break;
         bool emit = false; // a diffuse hit to record
         V3 n_P = mk3(0, 0, 0), n_N = mk3(0, 0, 0), n_view = mk3(0, 0, 0);
@@ -834,22 +872,38 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
         if (go) {
             if (!cur_valid) {
                 if (!color_active) {
-                    if (call == n_calls) {
+                    if (!task_active && aa_top != 0u) { // next task of aa_color's list
+                        --aa_top;
+                        t_cx = u2f(aa_stack[(3u * aa_top + 0u) * n_lp]);
+                        t_cy = u2f(aa_stack[(3u * aa_top + 1u) * n_lp]);
+                        t_level = aa_stack[(3u * aa_top + 2u) * n_lp];
+                        t_corner = 0;
+                        task_active = true;
+                    }
+                    if (!task_active) {
                         // render() epilogue (main.cu:339-346) happens in the sum kernel
                         w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_END_PIXEL;
                         ++cnt;
                         done = true;
                     } else {
-                        // aa_color (main.cu:230-304): level-0 task = pixel centre, level-1 task = 4 corners
+                        // box of this task: pixel size halved (aa_iter - level) times (main.cu:251,297)
+                        float sx = pix_w, sy = pix_h;
+                        for (uint32_t k = t_level; k < aa_iter; ++k) {
+                            sx = sx * 0.5f;
+                            sy = sy * 0.5f;
+                        }
+                        const float hx = sx * 0.5f, hy = sy * 0.5f;
+                        const float ox = (t_corner & 1u) ? 1.0f : -1.0f, oy = (t_corner & 2u) ? 1.0f : -1.0f;
                         float rx, ry;
-                        if (aa_iter == 0u) {
-                            rx = x_world;
-                            ry = y_world;
-                        } else {
-                            float hx = pix_w * 0.5f, hy = pix_h * 0.5f;
-                            float ox = (call & 1u) ? 1.0f : -1.0f, oy = (call & 2u) ? 1.0f : -1.0f;
-                            rx = x_world + ox * hx * 0.5f;
-                            ry = y_world + oy * hy * 0.5f;
+                        if (t_level == 0u) { // one sample at the centre
+                            rx = t_cx;
+                            ry = t_cy;
+                        } else if (t_level == 1u) { // four samples at the quarter points
+                            rx = t_cx + ox * hx * 0.5f;
+                            ry = t_cy + oy * hy * 0.5f;
+                        } else { // four samples at the box corners, compared afterwards
+                            rx = t_cx + ox * hx;
+                            ry = t_cy + oy * hy;
                         }
                         // Camera::getRay (Camera.hpp:86-144)
                         V3 ro, rd;
@@ -873,10 +927,13 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
                     }
                 } else if (nframes == 0) {
                     // color() returned (main.cu:225): the sum kernel folds it into the pixel
-                    w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_END_CALL;
+                    w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)(TAG_END_CALL | (t_level << 2) | (t_corner << 5));
                     ++cnt;
                     color_active = false;
-                    ++call;
+                    if (t_level == 0u || ++t_corner == 4u) {
+                        task_active = false;
+                        waiting = t_level >= 2u; // whether to subdivide depends on the four colours (main.cu:283-300)
+                    }
                 } else {
                     // pop the next child of the innermost frame (children leave last-to-first)
                     uint32_t* f = w.frames + ((size_t)(nframes - 1u) * WF_FRAME_PLANES) * n_lp + lp;
@@ -1091,7 +1148,8 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
         a.counters[pix] += cnt_shade;
         a.counters[npix + pix] += cnt_expand;
         uint32_t* s = w.state + lp;
-        s[ST_CTL * n_lp] = (done ? 1u : 0u) | (color_active ? 2u : 0u) | (cur_valid ? 4u : 0u) | (call << 4) | (nframes << 8);
+        s[ST_CTL * n_lp] = (done ? 1u : 0u) | (color_active ? 2u : 0u) | (cur_valid ? 4u : 0u) | (task_active ? 8u : 0u) |
+                           (waiting ? 16u : 0u) | (t_level << 5) | (t_corner << 8) | (aa_top << 12) | (nframes << 16);
         if (!done) {
             s[(ST_CUR_O + 0) * n_lp] = f2u(cur_o.x);
             s[(ST_CUR_O + 1) * n_lp] = f2u(cur_o.y);
@@ -1109,6 +1167,8 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
             s[(ST_RAY_D + 1) * n_lp] = f2u(ray_d.y);
             s[(ST_RAY_D + 2) * n_lp] = f2u(ray_d.z);
             s[ST_ON_STACK * n_lp] = on_stack;
+            s[ST_T_CX * n_lp] = f2u(t_cx);
+            s[ST_T_CY * n_lp] = f2u(t_cy);
         }
     } else if (first) {
         w.state[ST_CTL * n_lp + lp] = 1u; // pixel slots outside the image never run
@@ -1436,22 +1496,43 @@ __global__ void __launch_bounds__(64) wf_sum_kernel(WfArgs w, uint32_t first) {
     const size_t lp = (size_t)unit * 64u + lane;
     const uint32_t cnt = w.slot_count[lp];
     if (cnt == 0u && !first) return;
-    V4 final_c = V4{0, 0, 0, 0}, acc = V4{0, 0, 0, 0};
+    V4 final_c = V4{0, 0, 0, 0}, acc = V4{0, 0, 0, 0}, c0 = V4{0, 0, 0, 0};
+    bool all_equal = true;
     if (!first) {
-        const float4 f = w.px_acc[lp], g = w.px_acc[n_lp + lp];
+        const float4 f = w.px_acc[lp], g = w.px_acc[n_lp + lp], h = w.px_acc[2 * n_lp + lp];
         final_c = V4{f.x, f.y, f.z, f.w};
         acc = V4{g.x, g.y, g.z, g.w};
+        c0 = V4{h.x, h.y, h.z, h.w};
+        all_equal = (w.aa_verdict[lp] >> 8) & 1u;
     }
-    // weights of aa_color for a level-0 / level-1 task (main.cu:254-268)
-    const float mult = 1.0f / (float)(1u << 0);
+    const uint32_t aa_iter = a.aa_iter > 4u ? 4u : a.aa_iter; // main.cu:233
+    uint32_t verdict = AA_PENDING;
     for (uint32_t k = 0; k < cnt; ++k) {
         const uint32_t tag = w.tags[(size_t)k * n_lp + lp];
-        if (tag == TAG_ADD) {
+        const uint32_t type = tag & 3u;
+        if (type == TAG_ADD) {
             const float4 c = w.contrib[(size_t)k * n_lp + lp];
             final_c = final_c + V4{c.x, c.y, c.z, c.w};
-        } else if (tag == TAG_END_CALL) {
-            if (a.aa_iter == 0u) acc = acc + final_c * mult;
-            else acc = acc + (final_c * mult) * 0.25f;
+        } else if (type == TAG_END_CALL) {
+            // aa_color's use of a finished color() call (main.cu:254-300)
+            const uint32_t level = (tag >> 2) & 7u, corner = (tag >> 5) & 3u;
+            const float mult = 1.0f / (float)(1u << (2u * (aa_iter - level)));
+            if (level == 0u) {
+                acc = acc + final_c * mult;
+            } else if (level == 1u) {
+                acc = acc + (final_c * mult) * 0.25f;
+            } else {
+                if (corner == 0u) {
+                    c0 = final_c;
+                    all_equal = true;
+                } else if (all_equal && !equal4(final_c, c0)) {
+                    all_equal = false;
+                }
+                if (corner == 3u) {
+                    if (all_equal) acc = acc + c0 * mult;
+                    verdict = all_equal ? AA_ALL_EQUAL : AA_SUBDIVIDE; // the trace kernel waits for this
+                }
+            }
             final_c = V4{0, 0, 0, 0};
         } else {
             // render() epilogue (main.cu:339-346)
@@ -1462,6 +1543,8 @@ __global__ void __launch_bounds__(64) wf_sum_kernel(WfArgs w, uint32_t first) {
     }
     w.px_acc[lp] = make_float4(final_c.x, final_c.y, final_c.z, final_c.w);
     w.px_acc[n_lp + lp] = make_float4(acc.x, acc.y, acc.z, acc.w);
+    w.px_acc[2 * n_lp + lp] = make_float4(c0.x, c0.y, c0.z, c0.w);
+    w.aa_verdict[lp] = verdict | (all_equal ? 0x100u : 0u);
 }
 
 int g_resident_cus[64] = {0};
@@ -1547,7 +1630,7 @@ void build_jump_table(uint32_t nsteps, uint32_t* tab) {
 
 } // namespace
 
-bool wavefront_supports(const RenderArgs& args) { return args.aa_iter <= 1u; }
+bool wavefront_supports(const RenderArgs&) { return true; }
 
 void wavefront_release(WfWorkspace& ws) {
     (void)hipFree(ws.ctrs);
@@ -1558,6 +1641,7 @@ void wavefront_release(WfWorkspace& ws) {
     (void)hipFree(ws.contrib);
     (void)hipFree(ws.slot_count);
     (void)hipFree(ws.px_acc);
+    (void)hipFree(ws.aa_verdict);
     (void)hipFree(ws.work);
     (void)hipFree(ws.shadow_cnt);
     (void)hipFree(ws.queue);
@@ -1574,7 +1658,9 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     if (n_lp == 0) return hipSuccess;
     // Slots one pixel can fill in total: per color() call one per popped ray that can end in a hit or a
     // miss (1 + ind + ind^2 + ...), one end-of-call marker; one end-of-pixel marker.
-    const uint64_t calls = args.aa_iter == 0u ? 1u : 4u;
+    // color() calls a pixel can make before it has to wait for a verdict on its colours: 1 (aa_iter 0),
+    // 4 (aa_iter 1), else a level-2 task's four subtasks of four calls
+    const uint64_t calls = args.aa_iter == 0u ? 1u : (args.aa_iter == 1u ? 4u : 16u);
     uint64_t rays = 1, level = 1;
     for (uint32_t g = 0; g < args.gl_iter && rays < (1ull << 32); ++g) {
         level *= args.ind_rays;
@@ -1620,7 +1706,8 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     grab((void**)&ws.tags, (size_t)quota * n_lp);
     grab((void**)&ws.contrib, (size_t)quota * n_lp * 16u);
     grab((void**)&ws.slot_count, (size_t)n_lp * 4u);
-    grab((void**)&ws.px_acc, (size_t)2u * n_lp * 16u);
+    grab((void**)&ws.px_acc, (size_t)3u * n_lp * 16u);
+    grab((void**)&ws.aa_verdict, (size_t)n_lp * 4u);
     grab((void**)&ws.work, (size_t)WF_WORK_PLANES * cap_work * 4u);
     grab((void**)&ws.shadow_cnt, (size_t)lights * cap_work * 4u);
     grab((void**)&ws.queue, (size_t)3u * qcap * 4u);
@@ -1672,6 +1759,7 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     w.contrib = reinterpret_cast<float4*>(ws.contrib);
     w.slot_count = ws.slot_count;
     w.px_acc = reinterpret_cast<float4*>(ws.px_acc);
+    w.aa_verdict = ws.aa_verdict;
     w.work = ws.work;
     w.shadow_cnt = ws.shadow_cnt;
     w.queue = ws.queue;

@@ -211,11 +211,11 @@ int crt_scatter_shards(crt_ctx* ctx, uint32_t nx, uint32_t ny, uint32_t world,
 int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out);
 
 /* Which kernels crt_render / crt_render_partial / crt_render_shard run.  Both give the same bits.
- *   CRT_PIPELINE_AUTO        wavefront where it applies (aa_iter <= 1), else persistent (default)
- *   CRT_PIPELINE_PERSISTENT  one persistent kernel per launch, asynchronous on `stream`
+ *   CRT_PIPELINE_AUTO        the wavefront pipeline (default)
+ *   CRT_PIPELINE_PERSISTENT  one persistent kernel per launch, asynchronous on `stream`, no workspace
  *   CRT_PIPELINE_WAVEFRONT   trace / filter / resolve / shade / sum kernels with records in device
  *                            memory; the call returns after the image is complete (it synchronises
- *                            `stream` once per round); CRT_ERR_UNSUPPORTED at render time if aa_iter > 1
+ *                            `stream` at least once per round)
  * The reference has one kernel and no such switch (main.cu:328-347). */
 #define CRT_PIPELINE_AUTO 0
 #define CRT_PIPELINE_PERSISTENT 1

@@ -279,14 +279,20 @@ def test_wavefront_rounds_with_a_tiny_workspace(oracle, n, aa, gl, ind, S):
 
 
 @pytest.mark.gpu
-def test_wavefront_rejects_adaptive_aa_when_forced():
+@pytest.mark.parametrize("n,aa,gl,ind,S,limit", [(40, 2, 0, 75, 10, None), (32, 4, 0, 75, 6, None), (24, 3, 1, 5, 4, None),
+                                                  (20, 4, 1, 4, 3, 1 << 20), (16, 2, 2, 3, 2, 1 << 20)])
+def test_wavefront_adaptive_aa(oracle, n, aa, gl, ind, S, limit):
+    """aa_iter >= 2: whether a box is subdivided depends on the colours of its four corners
+    (main.cu:283-300), so the traversal parks at every such comparison and resumes in the next round."""
     ctx = _wavefront_ctx()
     try:
-        st = crt.make_settings(nx=8, ny=8, aa_iter=2, gl_iter=0)
-        ctx.upload(crt.cornell_box(4))
-        ctx.rng_init(8, 8, 1)
-        with pytest.raises(crt.CrtError):
-            ctx.render_to_host(st)
+        if limit:
+            ctx.set_workspace_limit(limit)
+        st = crt.make_settings(nx=n, ny=n, aa_iter=aa, gl_iter=gl, ind_rays=ind, shadowSamples=S)
+        fb, state = _gpu_render(ctx, crt.cornell_box(S), st, 11)
+        ref, _, ref_state = oracle.render(oracle.cornell(S), st, 11, want_state=True)
+        assert np.array_equal(state, ref_state)
+        assert np.array_equal(fb, ref)
     finally:
         ctx.close()
 
