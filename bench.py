@@ -104,6 +104,8 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
 
+    ctx.reserve_workspace(st, rank, world)  # allocation is set-up, not part of a step
+
     tiles_max = shard.shard_tiles_max(nx, ny, world)
     fb = torch.empty((ny, nx, 4), dtype=torch.float32, device=dev)
     compact = torch.empty(tiles_max * 64 * 4, dtype=torch.float32, device=dev) if world > 1 else None

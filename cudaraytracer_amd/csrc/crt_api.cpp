@@ -374,6 +374,23 @@ int crt_audit_result(crt_ctx* ctx, uint64_t* checked, uint64_t* contradictions) 
     return CRT_OK;
 }
 
+int crt_reserve_workspace(crt_ctx* ctx, const crt_settings* st, uint32_t rank, uint32_t world) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (world == 0 || rank >= world) return fail(ctx, CRT_ERR_INVALID, "rank %u out of world %u", rank, world);
+    int rc = check_settings(ctx, st);
+    if (rc != CRT_OK) return rc;
+    if ((rc = bind(ctx)) != CRT_OK) return rc;
+    if (ctx->pipeline == CRT_PIPELINE_PERSISTENT) return CRT_OK;
+    crt::RenderArgs a = base_args(ctx, st, nullptr);
+    a.mode = world == 1 ? crt::MODE_FULL : crt::MODE_SHARD;
+    a.rank = rank;
+    a.world = world;
+    a.n_units = world == 1 ? a.tiles_x * a.tiles_y : crt_shard_tiles(st->nx, st->ny, rank, world);
+    if (!crt::wavefront_supports(a)) return CRT_OK;
+    HIP_TRY(ctx, crt::wavefront_reserve(ctx->wf, a, ctx->scene_host.n_lights, ctx->workspace_limit));
+    return CRT_OK;
+}
+
 int crt_set_workspace_limit(crt_ctx* ctx, size_t bytes) {
     if (!ctx) return CRT_ERR_INVALID;
     if (bytes < ((size_t)1 << 20)) return fail(ctx, CRT_ERR_INVALID, "workspace limit below 1 MiB");

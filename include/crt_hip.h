@@ -235,6 +235,10 @@ int crt_get_kernel_times(crt_ctx* ctx, double ms[5], uint64_t launches[5]);
  * totals since the last crt_rng_init.  A correct build reports 0 contradictions.  Slow; off by default. */
 int crt_set_audit(crt_ctx* ctx, int enabled);
 int crt_audit_result(crt_ctx* ctx, uint64_t* checked, uint64_t* contradictions);
+/* Allocates the wavefront pipeline's workspace for crt_render (world == 1) or for
+ * crt_render_shard(rank, world) with these settings now, instead of inside the first render call.
+ * Optional; a no-op for the persistent pipeline.  Synchronous. */
+int crt_reserve_workspace(crt_ctx* ctx, const crt_settings* st, uint32_t rank, uint32_t world);
 /* Upper bound in bytes of the wavefront pipeline's device workspace (default 32 GiB); a smaller
  * bound means more rounds per image, never a different image.  No counterpart in the reference. */
 int crt_set_workspace_limit(crt_ctx* ctx, size_t bytes);
