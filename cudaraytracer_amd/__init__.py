@@ -18,6 +18,7 @@ from . import abi
 from .abi import make_settings  # noqa: F401  (re-export)
 
 _PKG = Path(__file__).resolve().parent
+# CRT_HIP_LIB selects another build of the same library (tools/variant_bench.sh compares kernel variants)
 LIB_PATH = Path(__import__("os").environ.get("CRT_HIP_LIB", _PKG / "libcrt_hip.so"))
 
 _lib = None

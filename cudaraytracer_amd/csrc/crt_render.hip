@@ -124,9 +124,6 @@ __global__ void __launch_bounds__(64, CRT_WAVES_PER_EU) render_kernel(RenderArgs
     Rng rng = {0, 0, 0, 0, 0, 0};
     uint32_t cnt_shade = 0, cnt_expand = 0;
     uint32_t w_stage2 = 0, w_glass = 0; // wave-uniform tallies of queued rays
-#ifdef CRT_DEBUG_SHADOW
-    float dbg_shadow = -1.0f;
-#endif
 
     // adaptive-AA task list (aa_color, main.cu:230-304)
     AATask aa_stack[10];
@@ -225,10 +222,6 @@ __global__ void __launch_bounds__(64, CRT_WAVES_PER_EU) render_kernel(RenderArgs
                             // render() epilogue (main.cu:339-346)
                             out[out_index] = make_float4(saturate_c(acc.x), saturate_c(acc.y), saturate_c(acc.z),
                                                          saturate_c(acc.w));
-#ifdef CRT_DEBUG_SHADOW
-                            out[out_index].w = dbg_shadow;
-                            out[out_index].x = acc.x;
-#endif
                             a.rng[0 * (size_t)npix + pix] = rng.v0;
                             a.rng[1 * (size_t)npix + pix] = rng.v1;
                             a.rng[2 * (size_t)npix + pix] = rng.v2;
@@ -634,9 +627,6 @@ __global__ void __launch_bounds__(64, CRT_WAVES_PER_EU) render_kernel(RenderArgs
             }
             if (act) {
                 shadowed += s_shadow[lane];
-#ifdef CRT_DEBUG_SHADOW
-                dbg_shadow = (float)shadowed;
-#endif
                 float visibility = 1.0f - ((float)shadowed / (float)S);
                 direct = direct + area_light_shade(ltc, L, gs, n_P, n_N, n_view, visibility);
             }
