@@ -264,6 +264,18 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
         }
         if (i >= in->n_geometry || in->geometry[i].kind != CRT_GEOM_QUAD || !out->uv[i].linear) continue;
         if (!(rabs > 0.0) || !(rabs < 1e6)) continue;
+        {
+            // The linear branch (Quad.hpp:255) is taken whenever |k2| < 1e-4, which also holds for trapezoids
+            // and for any small quad; its u = cross(kp, ka) / k1 with k1 = cross(kp, kg) - nor_id then accepts a
+            // region that is not the hull of the four vertices.  Only when kg (= v2 - v1 - v3 + v0 on the kept
+            // axes) is negligible against nor_id are (u, v) the affine coordinates of a parallelogram, and only
+            // then do the vertices bound the region: the relative change of k1 over the region stays below 1e-4,
+            // i.e. the boundary moves by less than a tenth of the margin.
+            const DevGeomUV& uvq = out->uv[i];
+            const double span = fabs((double)uvq.ka[0]) + fabs((double)uvq.ka[1]) + fabs((double)uvq.kb[0]) + fabs((double)uvq.kb[1]);
+            const double skew = fabs((double)uvq.kg[0]) + fabs((double)uvq.kg[1]);
+            if (!(skew * span <= 1e-5 * fabs((double)uvq.nor_id))) continue;
+        }
         const DevGeomHot& h = out->hot[i];
         const double nlen = sqrt((double)h.n[0] * h.n[0] + (double)h.n[1] * h.n[1] + (double)h.n[2] * h.n[2]);
         if (!(nlen > 1e-12) || !(nlen < 1e12)) continue;

@@ -183,6 +183,14 @@ def _custom_scene(mod, kind):
         for k, (x, y, z) in enumerate([(-0.9, -0.2, -0.9), (-0.2, -0.25, -0.7), (-0.25, 0.5, -0.75), (-0.85, 0.45, -0.95)]):
             pane.v[k].pos[0], pane.v[k].pos[1], pane.v[k].pos[2] = x, y, z
         geo.append(pane)
+    elif kind == "trapezoid":
+        # |k2| < 1e-4 (Quad.hpp:255 takes the linear branch) although v2 - v3 is 1.6x as long as v1 - v0: the
+        # accepted (u, v) region then reaches beyond the hull of the four vertices
+        q = abi.crt_geometry.from_buffer_copy(bytes(geo[2]))
+        for k, (x, y, z) in enumerate([(-0.22, -0.41, -1.17), (-0.15, -0.15, -0.85), (0.082, -0.144, -0.588), (-0.03, -0.56, -1.10)]):
+            q.v[k].pos[0], q.v[k].pos[1], q.v[k].pos[2] = x, y, z
+        geo.append(q)
+        lights[0].twoSided = 1
     elif kind == "uninitialised_area_light":
         lights[0].initialized = 0
     else:
@@ -191,7 +199,7 @@ def _custom_scene(mod, kind):
 
 
 @pytest.mark.parametrize("kind,gl", [("orthographic", 0), ("point_light", 1), ("two_lights_two_sided", 1),
-                                     ("skewed_quads", 1), ("uninitialised_area_light", 0)])
+                                     ("skewed_quads", 1), ("trapezoid", 1), ("uninitialised_area_light", 0)])
 def test_general_scenes_match_oracle(gpu_ctx, oracle, kind, gl):
     st = crt.make_settings(nx=40, ny=32, aa_iter=1, gl_iter=gl, ind_rays=6, shadowSamples=8)
     fb, state = _gpu_render(gpu_ctx, _custom_scene(crt, kind), st, 5)
@@ -298,7 +306,8 @@ def test_wavefront_adaptive_aa(oracle, n, aa, gl, ind, S, limit):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["cornell", "point_light", "two_lights_two_sided", "skewed_quads", "uninitialised_area_light"])
+@pytest.mark.parametrize("kind", ["cornell", "point_light", "two_lights_two_sided", "skewed_quads", "trapezoid",
+                                  "uninitialised_area_light"])
 def test_filter_decisions_agree_with_the_exact_test(kind):
     """Audit: every shadow ray the conservative filter decides is also run through the exact
     closest-hit test; no contradiction is allowed."""
@@ -351,3 +360,51 @@ def test_wavefront_redoes_a_round_when_the_ray_queue_overflows(oracle):
         assert np.array_equal(fb, ref)
     finally:
         ctx.close()
+
+
+# ------------------------------------------------------------------ seeded random scenes
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_scenes_match_oracle_and_pass_the_audit(oracle, seed):
+    """Random scenes (tests/scene_fuzz.py) through the wavefront pipeline with the audit on: bit-identical
+    image and RNG end states, and no conservative shadow-ray decision that the exact test contradicts."""
+    from scene_fuzz import random_scene
+    from cudaraytracer_amd import abi
+    S = 3 + seed % 7
+    st = crt.make_settings(nx=36, ny=28, aa_iter=1 + (seed % 5 == 4), gl_iter=1, ind_rays=5, shadowSamples=S)
+    scene = random_scene(crt, seed, S)
+    ctx = _wavefront_ctx()
+    try:
+        ctx.set_audit(True)
+        fb, state = _gpu_render(ctx, scene, st, 100 + seed)
+        checked, bad = ctx.audit_result()
+    finally:
+        ctx.close()
+    ref, _, ref_state = oracle.render(random_scene(oracle, seed, S), st, 100 + seed, want_state=True)
+    assert bad == 0, f"{bad} of {checked} filter decisions contradict the exact test"
+    assert np.array_equal(state, ref_state), "sample trees diverged"
+    if any(l.kind == abi.CRT_LIGHT_POINT for l in scene.lights):
+        assert np.abs(fb - ref).max() <= 1e-5  # powf in Blinn-Phong: device and host libm differ in the last ulp
+    else:
+        assert np.array_equal(fb, ref), f"{np.count_nonzero(fb != ref)} floats differ, max {np.abs(fb - ref).max()}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 6, 13, 20])
+def test_random_scenes_persistent_kernel(oracle, seed):
+    from scene_fuzz import random_scene
+    from cudaraytracer_amd import abi
+    st = crt.make_settings(nx=28, ny=20, aa_iter=2, gl_iter=1, ind_rays=4, shadowSamples=5)
+    scene = random_scene(crt, seed, 5)
+    ctx = crt.Context(0)
+    try:
+        ctx.set_pipeline(abi.CRT_PIPELINE_PERSISTENT)
+        fb, state = _gpu_render(ctx, scene, st, seed)
+    finally:
+        ctx.close()
+    ref, _, ref_state = oracle.render(random_scene(oracle, seed, 5), st, seed, want_state=True)
+    assert np.array_equal(state, ref_state)
+    if any(l.kind == abi.CRT_LIGHT_POINT for l in scene.lights):
+        assert np.abs(fb - ref).max() <= 1e-5
+    else:
+        assert np.array_equal(fb, ref)
