@@ -253,13 +253,18 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
             b.lo_in[k] = INFINITY;
             b.hi_in[k] = -INFINITY;
         }
-        b.pad[0] = b.pad[1] = 0.0f;
+        b.noise = INFINITY;
+        b.pad = 0.0f;
         if (i < in->n_geometry && in->geometry[i].kind == CRT_GEOM_QUAD && rabs > 0.0 && rabs < 1e6) {
             const DevGeomHot& hq = out->hot[i];
             const double n2 = (double)hq.n[0] * hq.n[0] + (double)hq.n[1] * hq.n[1] + (double)hq.n[2] * hq.n[2];
             if (n2 > 1e-24 && n2 < 1e24) {
                 b.n2 = (float)n2;
                 b.sp_min2 = (float)(1e-8 * n2 * rabs * rabs);
+                // |P|, |v0| <= sqrt(3) rabs and |D| <= 2 sqrt(3) rabs: the three products and two sums of a dot
+                // product, the rounding of P (or of the ray origin P + 0.01 d) and of the subtraction stay below
+                // 7e-7 |nor| rabs; two such computations are compared
+                b.noise = (float)(3e-6 * sqrt(n2) * rabs);
             }
         }
         if (i >= in->n_geometry || in->geometry[i].kind != CRT_GEOM_QUAD || !out->uv[i].linear) continue;

@@ -53,7 +53,10 @@ struct alignas(64) DevGeomBox {
     // For an axis-aligned rectangle the same box shrunk by the margin lies inside the quad: a plane
     // hit inside [lo_in, hi_in] on the kept axes certainly has 0 < u,v < 1.  lo_in = +inf otherwise.
     float lo_in[3], hi_in[3];
-    float pad[2];
+    // Bound on the absolute error of nor.(P - v0) and of nor.D (D a light-sample offset) in binary32, on either
+    // side of a comparison: 3e-6 * |nor| * scene size.  +inf when the quad is degenerate (nothing is decided).
+    float noise;
+    float pad;
     // The same boxes as centre and half-widths: |x - mid| > half_out rejects, |x - mid| < half_in is
     // inside the rectangle.  Unused axes: mid 0, half-widths +inf; no inner box: half_in -1.
     float mid[3], half_out[3], half_in[3];

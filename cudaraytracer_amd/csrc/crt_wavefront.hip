@@ -168,6 +168,10 @@ DI void stage_flush(const WfArgs& w, uint32_t (*stg)[kStageCap], Stage& st, uint
 //          or |sP| |D| < 0.005 |dnq| and the ray not grazing (P on the plane: the 0.01 step decides, t < 0);
 //          or opposite signs and (|sP| - |dnq|) |D| > 0.01002 |dnq| (t > |D|);
 //          or the plane point P - (sP/dnq) D is outside the quad's bounding box (DevGeomBox).
+//   In the second and third statement |sP| and |dnq| are replaced by the end of [x - N, x + N] that makes the
+//   statement harder, N = DevGeomBox::noise: rounding errors of the two dot products are absolute (they grow
+//   with the scene's coordinates), so for a grazing ray that meets the plane near its end they can exceed
+//   any relative margin.
 struct Classes {
     uint32_t sure_opaque, maybe_any, maybe_glass; // bit j = ray j
 };
@@ -217,7 +221,7 @@ DI Classes classify_block(ScenePtr sc, uint64_t prim_mask, V3 P, const V3 (&D)[N
         } else {
             const DevGeomBox CRT_CONST* bx = &sc->box[i];
             const V3 blo = ld3c(bx->lo), bhi = ld3c(bx->hi);
-            const float n2 = bx->n2, sp_min2 = bx->sp_min2;
+            const float n2 = bx->n2, sp_min2 = bx->sp_min2, nz = bx->noise;
             const V3 q = P - go;
             const float sP = __builtin_fmaf(q.x, gn.x, __builtin_fmaf(q.y, gn.y, q.z * gn.z));
             const float sP2 = sP * sP;
@@ -233,11 +237,12 @@ DI Classes classify_block(ScenePtr sc, uint64_t prim_mask, V3 P, const V3 (&D)[N
                 const bool a_ok = a[j] > 1e-6f && a[j] < 1e12f;
                 const bool same = sP * dnq > 0.0f;
                 const bool behind = same && off_plane;
-                const bool lifted = sP2 * a[j] < 2.5e-5f * dn2 && dn2 > 4e-6f * (n2 * a[j]);
-                const float e = __builtin_fabsf(sP) - __builtin_fabsf(dnq) * 1.000004f;
-                const bool beyond = !same && off_plane && e > 0.0f && (e * e) * a[j] > 1.004004e-4f * dn2;
+                const float ad = __builtin_fabsf(dnq), as = __builtin_fabsf(sP);
+                const float s_hi = as + nz, d_lo = ad - nz, d_hi = ad + nz;
+                const bool lifted = d_lo > 0.0f && (s_hi * s_hi) * a[j] < 2.5e-5f * (d_lo * d_lo) && dn2 > 4e-6f * (n2 * a[j]);
+                const float e = (as - nz) - d_hi * 1.000004f;
+                const bool beyond = !same && off_plane && e > 0.0f && (e * e) * a[j] > 1.004004e-4f * (d_hi * d_hi);
                 // plane point times dnq, against the box times |dnq|
-                const float ad = __builtin_fabsf(dnq);
                 const float sg = dnq < 0.0f ? -1.0f : 1.0f;
                 const float qx = __builtin_fmaf(P.x, dnq, -(sP * D[j].x)) * sg;
                 const float qy = __builtin_fmaf(P.y, dnq, -(sP * D[j].y)) * sg;
@@ -313,6 +318,7 @@ struct SphSlot {
 };
 struct QuadSlot {
     float sP, d0, d1, d2;
+    float s_lo, s_hi; // |sP| -+ the noise bound
     float q[3][3]; // [axis][1, u, v]
     bool offp;
 };
@@ -363,11 +369,13 @@ DI uint32_t sph_slot_class(const SphSlot& s, float u, float v) {
     return (disc > s.M2 && bq < -s.kc) ? 2u : 1u;
 }
 
-DI QuadSlot make_quad_slot(V3 P, V3 v0, V3 nor, float sp_min2, V3 Bp, const LightF& lf) {
+DI QuadSlot make_quad_slot(V3 P, V3 v0, V3 nor, float sp_min2, float nz, V3 Bp, const LightF& lf) {
     QuadSlot q;
     const V3 pq = P - v0;
     q.sP = fdot(pq, nor);
     q.offp = q.sP * q.sP > sp_min2;
+    q.s_lo = __builtin_fabsf(q.sP) - nz;
+    q.s_hi = __builtin_fabsf(q.sP) + nz;
     q.d0 = fdot(nor, Bp);
     q.d1 = fdot(nor, lf.e01);
     q.d2 = fdot(nor, lf.e03);
@@ -385,19 +393,21 @@ DI QuadSlot make_quad_slot(V3 P, V3 v0, V3 nor, float sp_min2, V3 Bp, const Ligh
 // rectangles only): the plane lies between P and the sample (s_c = |sP|/|dnq| < 0.999), more than 0.011 of
 // ray length away from P (so t = s_c |D| - 0.01 > 0), the ray is not grazing, and the plane point is
 // inside the rectangle shrunk by the margin, where the reference's 0 <= u,v <= 1 certainly holds.
-DI uint32_t quad_slot_class(const QuadSlot& q, V3 blo, V3 bhi, V3 ilo, V3 ihi, float n2, const PolyA& pa, const LightF& lf,
-                            float u, float v) {
+DI uint32_t quad_slot_class(const QuadSlot& q, V3 blo, V3 bhi, V3 ilo, V3 ihi, float n2, float nz, const PolyA& pa,
+                            const LightF& lf, float u, float v) {
     const float dnq = __builtin_fmaf(q.d2, v, __builtin_fmaf(q.d1, u, q.d0));
     const float a = __builtin_fmaf(__builtin_fmaf(lf.g11, u, __builtin_fmaf(lf.g12x2, v, pa.h1x2)), u,
                                    __builtin_fmaf(__builtin_fmaf(lf.g22, v, pa.h2x2), v, pa.h0));
-    const float dn2 = dnq * dnq, sP2 = q.sP * q.sP;
+    const float dn2 = dnq * dnq;
     const float sd = q.sP * dnq;
     const bool same = sd > 0.0f;
     const bool behind = same && q.offp;
-    const bool lifted = sP2 * a < 2.5e-5f * dn2 && dn2 > 4e-6f * (n2 * a);
     const float ad = __builtin_fabsf(dnq);
-    const float e = __builtin_fabsf(q.sP) - ad * 1.000004f;
-    const bool beyond = !same && q.offp && e > 0.0f && (e * e) * a > 1.004004e-4f * dn2;
+    const float d_lo = ad - nz, d_hi = ad + nz;
+    const float dl2 = d_lo * d_lo, dh2 = d_hi * d_hi;
+    const bool lifted = d_lo > 0.0f && (q.s_hi * q.s_hi) * a < 2.5e-5f * dl2 && dn2 > 4e-6f * (n2 * a);
+    const float e = q.s_lo - d_hi * 1.000004f;
+    const bool beyond = !same && q.offp && e > 0.0f && (e * e) * a > 1.004004e-4f * dh2;
     const float sg = dnq < 0.0f ? -1.0f : 1.0f;
     const float qx = __builtin_fmaf(q.q[0][2], v, __builtin_fmaf(q.q[0][1], u, q.q[0][0])) * sg;
     const float qy = __builtin_fmaf(q.q[1][2], v, __builtin_fmaf(q.q[1][1], u, q.q[1][0])) * sg;
@@ -408,11 +418,11 @@ DI uint32_t quad_slot_class(const QuadSlot& q, V3 blo, V3 bhi, V3 ilo, V3 ihi, f
     if (behind || lifted || beyond || (outside && steep)) return 0u;
     const bool inside = qx > ilo.x * ad && qx < ihi.x * ad && qy > ilo.y * ad && qy < ihi.y * ad && qz > ilo.z * ad &&
                         qz < ihi.z * ad;
-    const bool between = sd < 0.0f && q.offp && steep && __builtin_fabsf(q.sP) < 0.999f * ad && sP2 * a > 1.21e-4f * dn2;
+    const bool between = sd < 0.0f && q.offp && steep && q.s_hi < 0.999f * d_lo && (q.s_lo * q.s_lo) * a > 1.21e-4f * dh2;
     return (inside && between) ? 2u : 1u;
 }
 
-DI QuadParSlot make_quad_par_slot(V3 P, V3 v0, V3 nor, float sp_min2, float n2, V3 mid, V3 Bp, const LightF& lf) {
+DI QuadParSlot make_quad_par_slot(V3 P, V3 v0, V3 nor, float sp_min2, float n2, float nz, V3 mid, V3 Bp, const LightF& lf) {
     QuadParSlot q;
     const V3 pq = P - v0;
     const float sP = fdot(pq, nor), dnq = fdot(nor, Bp);
@@ -421,11 +431,13 @@ DI QuadParSlot make_quad_par_slot(V3 P, V3 v0, V3 nor, float sp_min2, float n2, 
     const float sd = sP * dnq;
     q.behind = sd > 0.0f && offp;
     const float inf = __builtin_inff();
-    q.t_lift = __builtin_fminf(fdiv(2.5e-5f * dn2, sP2) * 0.9999f, fdiv(dn2, 4e-6f * n2) * 0.9999f);
-    const float e = __builtin_fabsf(sP) - ad * 1.000004f;
-    q.t_beyond = (!(sd > 0.0f) && offp && e > 0.0f) ? fdiv(1.004004e-4f * dn2, e * e) * 1.0001f : inf;
+    // |sP| and |dnq| at the end of [x - nz, x + nz] that makes each statement harder
+    const float s_lo = __builtin_fabsf(sP) - nz, s_hi = __builtin_fabsf(sP) + nz, d_lo = ad - nz, d_hi = ad + nz;
+    q.t_lift = d_lo > 0.0f ? __builtin_fminf(fdiv(2.5e-5f * (d_lo * d_lo), s_hi * s_hi) * 0.9999f, fdiv(dn2, 4e-6f * n2) * 0.9999f) : 0.0f;
+    const float e = s_lo - d_hi * 1.000004f;
+    q.t_beyond = (!(sd > 0.0f) && offp && e > 0.0f) ? fdiv(1.004004e-4f * (d_hi * d_hi), e * e) * 1.0001f : inf;
     q.t_steep = fdiv(dn2, 1e-4f * n2) * 0.9999f;
-    q.t_between = (sd < 0.0f && offp && __builtin_fabsf(sP) < 0.999f * ad) ? fdiv(1.21e-4f * dn2, sP2) * 1.0001f : inf;
+    q.t_between = (sd < 0.0f && offp && s_hi < 0.999f * d_lo) ? fdiv(1.21e-4f * (d_hi * d_hi), s_lo * s_lo) * 1.0001f : inf;
     const float sc_ = -fdiv(sP, dnq); // ray parameter of the plane (box margins cover the 1e-7 error)
     const float Pk[3] = {P.x, P.y, P.z}, Bk[3] = {Bp.x, Bp.y, Bp.z}, e1[3] = {lf.e01.x, lf.e01.y, lf.e01.z},
                 e3[3] = {lf.e03.x, lf.e03.y, lf.e03.z}, mk[3] = {mid.x, mid.y, mid.z};
@@ -457,7 +469,7 @@ struct RecordFilter {
     int sph_i[2], quad_i;
     bool sph_glass[2], quad_glass, quad_par;
     V3 blo, bhi, ilo, ihi;
-    float n2;
+    float n2, nz;
     uint64_t rest_mask;
     // per lane
     bool rec_ok;
@@ -506,6 +518,7 @@ DI RecordFilter make_record_filter(ScenePtr sc, uint32_t li, const LightF& lf, V
     f.hout = f.hin = mk3(0, 0, 0);
     f.blo = f.bhi = f.ilo = f.ihi = mk3(0, 0, 0);
     f.n2 = 0.0f;
+    f.nz = __builtin_inff();
     f.rest_mask = prim_mask;
     f.rec_ok = true;
     f.pa.h0 = f.pa.h1x2 = f.pa.h2x2 = 0.0f;
@@ -551,17 +564,18 @@ DI RecordFilter make_record_filter(ScenePtr sc, uint32_t li, const LightF& lf, V
         const DevGeomBox CRT_CONST* bx = &sc->box[iq];
         f.quad_par = sc->quad_par[li][iq] != 0u;
         if (f.quad_par) {
-            f.qp = make_quad_par_slot(P, ld3c(g->o), ld3c(g->n), bx->sp_min2, bx->n2, ld3c(bx->mid), f.Bp0, lf);
+            f.qp = make_quad_par_slot(P, ld3c(g->o), ld3c(g->n), bx->sp_min2, bx->n2, bx->noise, ld3c(bx->mid), f.Bp0, lf);
             f.hout = ld3c(bx->half_out);
             f.hin = ld3c(bx->half_in);
         } else {
-            f.q = make_quad_slot(P, ld3c(g->o), ld3c(g->n), bx->sp_min2, f.Bp0, lf);
+            f.q = make_quad_slot(P, ld3c(g->o), ld3c(g->n), bx->sp_min2, bx->noise, f.Bp0, lf);
         }
         f.blo = ld3c(bx->lo);
         f.bhi = ld3c(bx->hi);
         f.ilo = ld3c(bx->lo_in);
         f.ihi = ld3c(bx->hi_in);
         f.n2 = bx->n2;
+        f.nz = bx->noise;
         f.quad_i = iq;
         f.quad_glass = g->mat_type == CRT_MAT_REFRACTIVE;
         f.rest_mask &= ~(1ull << iq);
@@ -606,7 +620,7 @@ DI Classes classify_samples(ScenePtr sc, const LightF& lf, const RecordFilter& f
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const uint32_t c = f.quad_par ? quad_par_slot_class(f.qp, f.hout, f.hin, f.pa, lf, us[j], vs[j])
-                                              : quad_slot_class(f.q, f.blo, f.bhi, f.ilo, f.ihi, f.n2, f.pa, lf, us[j], vs[j]);
+                                              : quad_slot_class(f.q, f.blo, f.bhi, f.ilo, f.ihi, f.n2, f.nz, f.pa, lf, us[j], vs[j]);
                 if (f.quad_glass) {
                     if (c != 0u) {
                         k.maybe_any |= 1u << j;
@@ -712,7 +726,7 @@ DI uint32_t record_light_class(ScenePtr sc, uint32_t li, const LightF& lf, V3 P)
             all_sure = lb > s.M2 && bqmax < -s.kc;
         } else if (sc->quad_par[li][i] != 0u) {
             const DevGeomBox CRT_CONST* bx = &sc->box[i];
-            const QuadParSlot q = make_quad_par_slot(P, ld3c(g->o), ld3c(g->n), bx->sp_min2, bx->n2, ld3c(bx->mid), Bp, lf);
+            const QuadParSlot q = make_quad_par_slot(P, ld3c(g->o), ld3c(g->n), bx->sp_min2, bx->n2, bx->noise, ld3c(bx->mid), Bp, lf);
             const float hout[3] = {bx->half_out[0], bx->half_out[1], bx->half_out[2]};
             const float hin[3] = {bx->half_in[0], bx->half_in[1], bx->half_in[2]};
             bool out_all = false, in_all = true;
@@ -1329,7 +1343,15 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
                     const bool exact_opaque = h.idx >= 0 && h.mat_type != CRT_MAT_REFRACTIVE;
                     const bool exact_free = h.idx < 0;
                     ++decided;
-                    if (covered ? !exact_opaque : !exact_free) ++bad;
+                    if (covered ? !exact_opaque : !exact_free) {
+                        ++bad;
+#ifdef CRT_AUDIT_TRACE // build with -DCRT_AUDIT_TRACE to see the offending rays
+                        printf("audit: record %u light %u sample %u P=(%.9g %.9g %.9g) u=%.9g v=%.9g decided %s (record class %u), "
+                               "exact hit %d mat %u t=%.9g of %.9g, origin (%.9g %.9g %.9g) dir (%.9g %.9g %.9g)\n",
+                               wi, li, s, P.x, P.y, P.z, u, v, covered ? "blocked" : "free", rec_class, h.idx, h.mat_type, h.t, x,
+                               o.x, o.y, o.z, d.x, d.y, d.z);
+#endif
+                    }
                 }
             }
         }

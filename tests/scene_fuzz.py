@@ -27,14 +27,24 @@ def _random_frame(rng, lo, hi):
             return _unit(a) * rng.uniform(lo, hi), _unit(b) * rng.uniform(lo, hi)
 
 
-def random_scene(mod, seed, shadow_samples=6):
+def random_scene(mod, seed, shadow_samples=6, wild=False):
+    """wild: also a random scale of the whole scene (the reference's 0.01 ray offsets do not scale with it), a
+    camera that is moved, turned or orthographic, lights anywhere in the box, and mostly glass."""
     rng = np.random.default_rng(seed)
+    wrng = np.random.default_rng(seed + 7_000_000)
+    scale = 1.0
+    glassy = False
+    if wild:
+        scale = float(wrng.choice([0.05, 0.3, 1.0, 1.0, 4.0, 50.0]))
+        glassy = wrng.random() < 0.4
     base = crt.cornell_box(shadow_samples)
     clone = lambda g: abi.crt_geometry.from_buffer_copy(bytes(g))
     mirror, glass, diffuse = base.geometry[0].mat, base.geometry[1].mat, [g.mat for g in base.geometry[2:7]]
 
     def material():
         kind = rng.integers(0, 3)
+        if glassy and wrng.random() < 0.7:
+            kind = 2
         if kind == 0:
             return diffuse[rng.integers(0, len(diffuse))]
         if kind == 1:
@@ -90,6 +100,8 @@ def random_scene(mod, seed, shadow_samples=6):
         pts = [p0, p0 + e1, p0 + a * e1 + b * e2, p0 + e2]
         for k in range(4):
             _set3(l.points[k], pts[k])
+        if wild and wrng.random() < 0.5:
+            _set3(l.pos, (wrng.uniform(-0.9, 0.9), wrng.uniform(-0.9, 0.9), wrng.uniform(-1.9, -0.3)))
         l.twoSided = int(rng.random() < 0.5)
         l.intensity = float(rng.uniform(2.0, 12.0))
         l.shadowSamples = shadow_samples
@@ -98,4 +110,25 @@ def random_scene(mod, seed, shadow_samples=6):
         lights.append(abi.crt_light(abi.CRT_LIGHT_POINT, (float(rng.uniform(-0.5, 0.5)), 0.5, -1.0),
                                     (1.0, 0.9, 0.8, 1.0), 0.5))
     cam = abi.crt_camera.from_buffer_copy(bytes(base.camera))
+    if wild:
+        if wrng.random() < 0.5:
+            _set3(cam.pos, (wrng.uniform(-0.7, 0.7), wrng.uniform(-0.7, 0.7), wrng.uniform(-1.2, 0.5)))
+            _set3(cam.front, _unit(np.array((wrng.uniform(-0.6, 0.6), wrng.uniform(-0.6, 0.6), -1.0))))
+        if wrng.random() < 0.2:
+            cam.type = abi.CRT_CAM_ORTHOGRAPHIC
+            cam.orthoScale = float(wrng.uniform(0.3, 1.2)) * scale
+        for g in geo:
+            for k in range(3):
+                g.center[k] *= scale
+            g.radius *= scale
+            for v in g.v:
+                for k in range(3):
+                    v.pos[k] *= scale
+        for l in lights:
+            for k in range(3):
+                l.pos[k] *= scale
+                for pt in l.points:
+                    pt[k] *= scale
+        for k in range(3):
+            cam.pos[k] *= scale
     return mod.Scene(cam, geo, lights)

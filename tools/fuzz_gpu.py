@@ -1,4 +1,4 @@
-"""Long form of the random-scene parity test: python tools/fuzz_gpu.py FIRST COUNT (needs a GPU)."""
+"""Long form of the random-scene parity test: python tools/fuzz_gpu.py FIRST COUNT [wild] (needs a GPU)."""
 import sys
 from pathlib import Path
 
@@ -12,23 +12,26 @@ import oracle_lib  # noqa: E402
 from scene_fuzz import random_scene  # noqa: E402
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
+wild = len(sys.argv) > 3 and sys.argv[3] == "wild"
 failures = 0
 for seed in range(first, first + count):
     S = 3 + seed % 7
     gl = 2 if seed % 11 == 10 else 1
-    st = crt.make_settings(nx=36, ny=28, aa_iter=1 + (seed % 5 == 4), gl_iter=gl, ind_rays=5 if gl == 1 else 3,
+    st = crt.make_settings(nx=36, ny=28, aa_iter=(1, 1, 1, 1, 2, 1, 3, 1, 0, 4)[seed % 10], gl_iter=gl, ind_rays=5 if gl == 1 else 3,
                            shadowSamples=S)
-    scene = random_scene(crt, seed, S)
+    scene = random_scene(crt, seed, S, wild)
     ctx = crt.Context(0)
-    ctx.set_pipeline(abi.CRT_PIPELINE_WAVEFRONT)
+    ctx.set_pipeline(abi.CRT_PIPELINE_PERSISTENT if seed % 8 == 5 else abi.CRT_PIPELINE_WAVEFRONT)
     ctx.set_audit(True)
+    if seed % 7 == 3:
+        ctx.set_workspace_limit(1 << 20)
     ctx.upload(scene)
     ctx.rng_init(st.nx, st.ny, seed)
     fb = ctx.render_to_host(st)
     state = ctx.rng_export(st.nx, st.ny)
     checked, bad = ctx.audit_result()
     ctx.close()
-    ref, _, ref_state = oracle_lib.render(random_scene(oracle_lib, seed, S), st, seed, want_state=True)
+    ref, _, ref_state = oracle_lib.render(random_scene(oracle_lib, seed, S, wild), st, seed, want_state=True)
     point = any(l.kind == abi.CRT_LIGHT_POINT for l in scene.lights)
     same = np.abs(fb - ref).max() <= 1e-5 if point else np.array_equal(fb, ref)
     ok = bad == 0 and same and np.array_equal(state, ref_state)
