@@ -58,6 +58,7 @@ def lib():
             "crt_stats_since_init": (C.c_int, [C.c_void_p, P(abi.crt_settings), P(abi.crt_stats)]),
             "crt_selftest_rcp": (C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint32)]),
             "crt_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
+            "crt_set_trace_mode": (C.c_int, [C.c_void_p, C.c_int]),
             "crt_set_workspace_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
             "crt_reserve_workspace": (C.c_int, [C.c_void_p, P(abi.crt_settings), C.c_uint32, C.c_uint32]),
             "crt_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
@@ -84,6 +85,7 @@ ABI_SYMBOLS = (
     "crt_create", "crt_destroy", "crt_last_error", "crt_cornell_scene", "crt_scene_upload", "crt_rng_init",
     "crt_rng_export", "crt_render", "crt_render_partial", "crt_render_shard", "crt_shard_tiles",
     "crt_shard_tiles_max", "crt_scatter_shards", "crt_stats_since_init", "crt_selftest_rcp", "crt_set_pipeline",
+    "crt_set_trace_mode",
     "crt_set_workspace_limit", "crt_reserve_workspace", "crt_set_audit", "crt_audit_result", "crt_set_timing",
     "crt_get_kernel_times", "crt_fb_alloc", "crt_fb_free",
     "crt_fb_download", "crt_write_hdr", "crt_encode_hdr", "crt_to_rgba8", "crt_write_ppm")
@@ -177,6 +179,10 @@ class Context:
     def set_pipeline(self, pipeline):
         """abi.CRT_PIPELINE_AUTO / _PERSISTENT / _WAVEFRONT."""
         self._check(lib().crt_set_pipeline(self._h, pipeline), "crt_set_pipeline")
+
+    def set_trace_mode(self, mode):
+        """abi.CRT_TRACE_AUTO / _PER_PIXEL / _COOPERATIVE (wavefront pipeline, gl_iter >= 1)."""
+        self._check(lib().crt_set_trace_mode(self._h, mode), "crt_set_trace_mode")
 
     def reserve_workspace(self, settings, rank=0, world=1):
         self._check(lib().crt_reserve_workspace(self._h, C.byref(settings), rank, world), "crt_reserve_workspace")

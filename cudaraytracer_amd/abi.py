@@ -3,6 +3,7 @@ import ctypes as C
 
 CRT_OK = 0
 CRT_PIPELINE_AUTO, CRT_PIPELINE_PERSISTENT, CRT_PIPELINE_WAVEFRONT = 0, 1, 2
+CRT_TRACE_AUTO, CRT_TRACE_PER_PIXEL, CRT_TRACE_COOPERATIVE = 0, 1, 2
 CRT_ERR_INVALID = -1
 CRT_ERR_HIP = -2
 CRT_ERR_NO_SCENE = -3

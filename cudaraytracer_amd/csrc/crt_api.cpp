@@ -29,6 +29,7 @@ struct crt_ctx {
     uint32_t rng_nx = 0, rng_ny = 0;
     int pipeline = CRT_PIPELINE_AUTO;
     int audit = 0;
+    int trace_mode = CRT_TRACE_AUTO;
     size_t workspace_limit = (size_t)32 << 30;
     crt::WfWorkspace wf;
 };
@@ -98,8 +99,16 @@ crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
     return a;
 }
 
+// Whether the trace kernel of this launch expands the last GI level cooperatively (only on request:
+// it has not measured faster than the per-pixel walk at any launch size).
+uint32_t pick_cooperative(const crt_ctx* ctx, const crt::RenderArgs& a) {
+    return (a.gl_iter != 0 && ctx->trace_mode == CRT_TRACE_COOPERATIVE) ? 1u : 0u;
+}
+
 // Runs one launch through the pipeline the context selects.
-int run_render(crt_ctx* ctx, const crt::RenderArgs& a, hipStream_t stream) {
+int run_render(crt_ctx* ctx, const crt::RenderArgs& args, hipStream_t stream) {
+    crt::RenderArgs a = args;
+    a.cooperative = pick_cooperative(ctx, a);
     const bool can_wf = crt::wavefront_supports(a);
     if (ctx->pipeline == CRT_PIPELINE_WAVEFRONT && !can_wf)
         return fail(ctx, CRT_ERR_UNSUPPORTED, "the wavefront pipeline does not implement these settings");
@@ -355,6 +364,14 @@ int crt_get_kernel_times(crt_ctx* ctx, double ms[5], uint64_t launches[5]) {
     return CRT_OK;
 }
 
+int crt_set_trace_mode(crt_ctx* ctx, int mode) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (mode != CRT_TRACE_AUTO && mode != CRT_TRACE_PER_PIXEL && mode != CRT_TRACE_COOPERATIVE)
+        return fail(ctx, CRT_ERR_INVALID, "unknown trace mode %d", mode);
+    ctx->trace_mode = mode;
+    return CRT_OK;
+}
+
 int crt_set_audit(crt_ctx* ctx, int enabled) {
     if (!ctx) return CRT_ERR_INVALID;
     ctx->audit = enabled ? 1 : 0;
@@ -387,6 +404,7 @@ int crt_reserve_workspace(crt_ctx* ctx, const crt_settings* st, uint32_t rank, u
     a.world = world;
     a.n_units = world == 1 ? a.tiles_x * a.tiles_y : crt_shard_tiles(st->nx, st->ny, rank, world);
     if (!crt::wavefront_supports(a)) return CRT_OK;
+    a.cooperative = pick_cooperative(ctx, a);
     HIP_TRY(ctx, crt::wavefront_reserve(ctx->wf, a, ctx->scene_host.n_lights, ctx->workspace_limit));
     return CRT_OK;
 }

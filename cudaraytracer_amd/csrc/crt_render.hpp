@@ -30,6 +30,7 @@ struct RenderArgs {
     uint32_t tx, ty, blocks_x, blocks_y, win_bx, win_by, start_bx, start_by; // MODE_PARTIAL
     uint32_t audit;           // wavefront pipeline: also run the filter audit kernel
     uint32_t max_shadow_rays; // shadow rays one diffuse hit casts: sum of shadowSamples over initialised area lights
+    uint32_t cooperative;     // wavefront pipeline: the trace kernel expands the last GI level with one lane per child ray
 };
 
 // ---- wavefront pipeline (crt_wavefront.hip)
@@ -58,6 +59,13 @@ struct WfWorkspace {
     uint32_t* jump_dev = nullptr;   // two generator jump tables
     uint32_t jump_n[2] = {0, 0};    // step counts the tables were built for
     uint32_t* qcounts = nullptr;    // entries per filter wave
+    uint32_t* unit_cost = nullptr;  // [n_units] cost estimate per work unit (float bits)
+    uint32_t* unit_order = nullptr; // [n_units] launch order of the trace kernel
+    uint32_t* unit_host = nullptr;  // pinned: [n_units] costs, then [n_units] order
+    // cooperative trace only
+    float* draws = nullptr;         // [2 * CRT_RAY_STACK][n_lp]: the (r1, r2) pairs of the innermost node's children
+    uint32_t* coop_tabs = nullptr;  // 14 jump tables: 1..7 and 8, 16, .., 56 shaded points' worth of draws
+    uint32_t coop_n = 0xffffffffu;  // draws per shaded point the tables were built for
     size_t bytes = 0;
     // optional per-kernel timing with HIP events on the launch stream (crt_set_timing)
     bool timing = false;

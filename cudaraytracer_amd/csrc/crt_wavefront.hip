@@ -28,6 +28,7 @@
 // reference, so results are bit-identical to the single-kernel path in crt_render.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "crt_device.hpp"
@@ -79,6 +80,9 @@ struct WfArgs {
     uint32_t* queue;
     uint32_t* qcounts;    // entries each filter wave left in its region of the queue
     uint32_t region_cap;  // queue entries per filter wave
+    const uint32_t* unit_order; // trace: launch slot -> work unit, most expensive first; null = identity
+    float* draws;              // cooperative trace: [2 * CRT_RAY_STACK][n_lp] child draws of the innermost leaf node
+    const uint32_t* coop_tabs; // cooperative trace: 14 rng_jump tables in device memory (kCoopTables)
 };
 
 DI float u2f(uint32_t x) { return __uint_as_float(x); }
@@ -757,7 +761,220 @@ DI uint32_t record_light_class(ScenePtr sc, uint32_t li, const LightF& lf, V3 P)
 
 // ---------------------------------------------------------------------------------------- trace
 constexpr uint32_t kTraceWaves = 4; // waves per trace workgroup (they share the generator jump tables in LDS)
-__global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w, uint32_t first) {
+// Cooperative expansion handles at most 63 children at a time, so that a 64th lane can compute the
+// generator state the pixel continues with; the k-th diffuse hit of a batch starts k shaded points'
+// worth of draws further on, k = 8a + b: tables 0..6 jump b = 1..7 points, tables 7..13 jump 8a points.
+constexpr uint32_t kCoopBatch = 63, kCoopTables = 14;
+
+// Children of the innermost frame leave last-to-first (main.cu:176-191 pushes, :132 pops):
+// get_random_ray_values_in_hemisphere (main.cu:60-74) and the child's attenuation (main.cu:186).
+DI void child_ray(V3 hp, V3 hn, V4 patt, V4 pdiff, float r1, float r2, float inv_ind, V3& o, V3& d, V4& att) {
+    V3 Nx, Nz;
+    surface_frame(hn, Nx, Nz);
+    const float PI_2 = 6.28318530717958647692f;
+    float sinTheta = 1.0f - r1 * r1;
+    float phi = r2 * PI_2;
+    float sp, cp;
+    sincos_c(phi, sp, cp);
+    float x = sinTheta * cp, z = sinTheta * sp;
+    V3 wd = mk3(x * Nz.x + r1 * hn.x + z * Nx.x, x * Nz.y + r1 * hn.y + z * Nx.y, x * Nz.z + r1 * hn.z + z * Nx.z);
+    o = hp + wd * 0.01f;
+    d = wd;
+    att = ((pdiff * (2.0f * r1)) * patt) * inv_ind;
+}
+
+// One pop of color()'s loop (main.cu:132-221) for a ray with bounces left, without the shading.
+enum : uint32_t { POP_MISS = 0, POP_DIFFUSE = 1, POP_BOUNCE = 2 };
+DI uint32_t pop_ray(ScenePtr sc, V3& cur_o, V3& cur_d, V4& cur_att, uint32_t& cur_ref, V3& ray_d, V3& P, V3& N,
+                    uint32_t& geom) {
+    if (!eps_equal(len_sq(cur_d), 0.0f, kEpsSq)) ray_d = normalize3(cur_d);
+    const V3 ro = cur_o;
+    Hit h = closest_hit(sc, ro, ray_d, 0.0f);
+    if (h.idx < 0) return POP_MISS;
+    hit_point_normal(sc, h, ro, ray_d, P, N);
+    geom = (uint32_t)h.idx;
+    if (h.mat_type == CRT_MAT_DIFFUSE) return POP_DIFFUSE;
+    if (h.mat_type == CRT_MAT_REFLECT) {
+        // get_reflect_ray (main.cu:76-81)
+        V3 I = normalize3(ray_d);
+        V3 rdir = reflect3(I, normalize3(N));
+        cur_o = P + rdir * 0.01f;
+        cur_d = rdir;
+    } else {
+        // get_refraction_ray (main.cu:83-108)
+        bool front_face = dot3(ray_d, N) < 0.0f;
+        V3 norm = front_face ? N : neg(N);
+        float ratio = sc->shade[h.idx].refract_index / 1.0f;
+        if (front_face) ratio = rcp_exact(ratio);
+        V3 rdn = normalize3(ray_d);
+        float cos_theta = __builtin_fminf(dot3(neg(rdn), norm), 1.0f);
+        float sin_theta = rcp_exact(rsqrt_c(1.0f - cos_theta * cos_theta));
+        bool cannot_refract = ratio * sin_theta > 1.0f; // reflectance(...) > 1 never holds
+        V3 dir = cannot_refract ? reflect3(rdn, norm) : refract3(rdn, norm, ratio);
+        cur_o = P + dir * 0.01f;
+        cur_d = dir;
+    }
+    cur_att = cur_att * ld4c(sc->shade[h.idx].diffuse);
+    cur_ref = cur_ref - 1u;
+    return POP_BOUNCE;
+}
+
+// Stores one shade record.
+DI void store_record(const WfArgs& w, uint32_t wi, V3 P, V3 N, V3 view, V4 att, uint32_t geom, const Rng& rng, uint32_t slot) {
+    if (wi < w.cap_work) {
+        uint32_t* r = w.work + wi;
+        const size_t cw = w.cap_work;
+        r[(WK_P + 0) * cw] = f2u(P.x);
+        r[(WK_P + 1) * cw] = f2u(P.y);
+        r[(WK_P + 2) * cw] = f2u(P.z);
+        r[(WK_N + 0) * cw] = f2u(N.x);
+        r[(WK_N + 1) * cw] = f2u(N.y);
+        r[(WK_N + 2) * cw] = f2u(N.z);
+        r[(WK_V + 0) * cw] = f2u(view.x);
+        r[(WK_V + 1) * cw] = f2u(view.y);
+        r[(WK_V + 2) * cw] = f2u(view.z);
+        r[(WK_ATT + 0) * cw] = f2u(att.x);
+        r[(WK_ATT + 1) * cw] = f2u(att.y);
+        r[(WK_ATT + 2) * cw] = f2u(att.z);
+        r[(WK_ATT + 3) * cw] = f2u(att.w);
+        r[WK_GEOM * cw] = geom;
+        r[(WK_RNG + 0) * cw] = rng.v0;
+        r[(WK_RNG + 1) * cw] = rng.v1;
+        r[(WK_RNG + 2) * cw] = rng.v2;
+        r[(WK_RNG + 3) * cw] = rng.v3;
+        r[(WK_RNG + 4) * cw] = rng.v4;
+        r[(WK_RNG + 5) * cw] = rng.d;
+        r[WK_SLOT * cw] = slot;
+    } else {
+        w.ctrs[WF_CTR_ERROR] = 1u;
+    }
+}
+
+// The wave's cursor into the shade-record array: records are handed out in chunks of kWorkChunk
+// consecutive indices, so the one global counter sees one atomic per chunk instead of one per step.
+struct WorkCursor {
+    uint32_t base, used; // wave-uniform
+    bool have;
+};
+// Record index for every lane of `em` (all lanes call this together).
+DI uint32_t reserve_records(const WfArgs& w, WorkCursor& wc, uint64_t em, uint32_t lane) {
+    const uint32_t n_emit = (uint32_t)__popcll(em);
+    const bool need_chunk = wc.used + n_emit > kWorkChunk;
+    uint32_t new_base = 0;
+    if (need_chunk) {
+        if (lane == (uint32_t)__builtin_ctzll(em)) new_base = atomicAdd(&w.ctrs[WF_CTR_WORK], kWorkChunk);
+        new_base = (uint32_t)__builtin_amdgcn_readlane((int)new_base, __builtin_ctzll(em));
+    }
+    const uint32_t my_pos = wc.used + lane_rank(em);
+    const uint32_t my_wi = my_pos < kWorkChunk ? wc.base + my_pos : new_base + (my_pos - kWorkChunk);
+    if (need_chunk) {
+        wc.base = new_base;
+        wc.used = wc.used + n_emit - kWorkChunk;
+        wc.have = true;
+    } else {
+        wc.used += n_emit;
+    }
+    return my_wi;
+}
+
+// get_world_coordinates (main.cu:306-314), pixel_size (main.cu:337) and Camera::getRay (Camera.hpp:86-144).
+struct CameraRays {
+    V3 pos, front, right, up, eye;
+    uint32_t type;
+    float ortho, pix_w, pix_h, width_world;
+    DI void ray(float rx, float ry, V3& ro, V3& rd) const {
+        if (type == CRT_CAM_ORTHOGRAPHIC) {
+            ro = ((right * rx) * ortho + (up * ry) * ortho) + pos;
+            rd = ray_dir(front);
+        } else {
+            ro = (right * rx + up * ry) + pos;
+            rd = ray_dir(ro - eye);
+        }
+    }
+    // centre of pixel (i, j): remap<float,true> (math_functions.hpp:31-45)
+    DI void pixel_centre(const RenderArgs& a, uint32_t i, uint32_t j, float& x_world, float& y_world) const {
+        float denom = (float)a.nx - 0.0f;
+        float es = -width_world * 0.5f, ee = width_world * 0.5f;
+        x_world = (denom == 0.0f) ? (float)i : es + ((ee - es) / denom) * ((float)i - 0.0f);
+        float denomy = (float)a.ny - 0.0f;
+        y_world = (denomy == 0.0f) ? (float)j : 1.0f + ((-1.0f - 1.0f) / denomy) * ((float)j - 0.0f);
+    }
+};
+DI CameraRays load_camera(ScenePtr sc, const RenderArgs& a) {
+    CameraRays c;
+    const float height_world = 2.0f;
+    c.width_world = height_world * ((float)a.nx / (float)a.ny);
+    c.pix_w = c.width_world / (float)a.nx;
+    c.pix_h = height_world / (float)a.ny;
+    c.pos = ld3c(sc->cam.pos);
+    c.front = ld3c(sc->cam.front);
+    c.right = ld3c(sc->cam.right);
+    c.up = ld3c(sc->cam.up);
+    c.eye = c.pos - c.front * (c.width_world * 0.5f * sc->cam.one_over_tan); // Camera.hpp:97-98,133-134
+    c.type = sc->cam.type;
+    float aspect = height_world / c.width_world;
+    c.ortho = sc->cam.ortho_scale * (aspect > 1.0f ? aspect : 1.0f);
+    return c;
+}
+
+// Launch order of the trace kernel's work units.  A wave lasts as long as its slowest pixel, and a pixel's
+// walk is one dependent chain, so a tile of expensive pixels that starts last leaves the GPU idle behind
+// it.  This kernel gives every unit a cost estimate: the primary ray of each pixel centre is followed to
+// its first diffuse hit, and the estimate grows with the part of the hemisphere there that mirrors and
+// glass cover (every GI child that meets one takes up to ref_iter more steps).  Ordering only; no result
+// depends on it.
+__global__ void __launch_bounds__(64) wf_cost_kernel(WfArgs w, uint32_t* unit_cost) {
+    const RenderArgs& a = w.r;
+    ScenePtr sc = (ScenePtr)a.scene;
+    const uint32_t lane = threadIdx.x, unit = blockIdx.x;
+    const PixelMap pm = map_pixel(a, unit, lane);
+    const CameraRays cam = load_camera(sc, a);
+    float cost = 0.0f;
+    if (pm.valid) {
+        float xw, yw;
+        cam.pixel_centre(a, pm.i, pm.j, xw, yw);
+        V3 o, d, ray_d = mk3(0.0f, 0.0f, -1.0f), P = mk3(0, 0, 0), N = mk3(0, 0, 1);
+        cam.ray(xw, yw, o, d);
+        V4 att = V4{1, 1, 1, 1};
+        uint32_t ref = a.ref_iter, geom = 0, what = POP_MISS;
+        float steps = 0.0f;
+        while (ref != 0u) {
+            what = pop_ray(sc, o, d, att, ref, ray_d, P, N, geom);
+            steps += 1.0f;
+            if (what != POP_BOUNCE) break;
+        }
+        cost = steps;
+        if (what == POP_DIFFUSE && a.gl_iter != 0u) {
+            float covered = 0.0f; // fraction of the hemisphere over P that bounces a child ray on
+            const uint32_t n = sc->n_geom;
+            for (uint32_t i = 0; i < n; ++i) {
+                const DevGeomHot CRT_CONST* g = &sc->hot[i];
+                if (g->mat_type == CRT_MAT_DIFFUSE) continue;
+                if (g->kind == CRT_GEOM_SPHERE) {
+                    const V3 c = ld3c(g->o) - P;
+                    const float d2 = fdot(c, c) + 1e-12f, r2 = g->n[0];
+                    const float dist = __builtin_amdgcn_sqrtf(d2), r = __builtin_amdgcn_sqrtf(r2);
+                    const float omega = 1.0f - __builtin_amdgcn_sqrtf(__builtin_fmaxf(0.0f, 1.0f - fdiv(r2, d2)));
+                    const float above = __builtin_fminf(__builtin_fmaxf(fdiv(fdot(N, c) + r, dist + r), 0.0f), 1.0f);
+                    covered += omega * above;
+                } else {
+                    const DevGeomBox CRT_CONST* bx = &sc->box[i];
+                    const V3 c = ld3c(g->o) - P, nq = ld3c(g->n); // |nq| = area of the spanning parallelogram
+                    const float d2 = fdot(c, c) + 1e-12f;
+                    const float area_cos = __builtin_fabsf(fdot(nq, c)) * __builtin_amdgcn_rsqf(d2);
+                    covered += __builtin_fminf(fdiv(area_cos, 6.2831853f * d2), 0.5f) * (bx->n2 > 0.0f ? 1.0f : 0.0f);
+                }
+            }
+            covered = __builtin_fminf(covered, 1.0f);
+            cost += (float)a.ind_rays * (1.0f + covered * (float)a.ref_iter);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) cost = __builtin_fmaxf(cost, __shfl_xor(cost, off, 64));
+    if (lane == 0) unit_cost[unit] = f2u(cost);
+}
+
+template <bool COOP>
+__global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kernel(WfArgs w, uint32_t first) {
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
     __shared__ __attribute__((aligned(16))) uint32_t s_jump[2][kJumpWords];
@@ -765,28 +982,16 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
         s_jump[k / kJumpWords][k % kJumpWords] = w.jump_tabs[k];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t unit = blockIdx.x * kTraceWaves + (threadIdx.x >> 6);
-    if (unit >= a.n_units) return;
+    const uint32_t launch_slot = blockIdx.x * kTraceWaves + (threadIdx.x >> 6);
+    if (launch_slot >= a.n_units) return;
+    const uint32_t unit = w.unit_order ? w.unit_order[launch_slot] : launch_slot; // most expensive units first
     const size_t n_lp = w.n_lp;
     const size_t lp = (size_t)unit * 64u + lane;
     const uint32_t npix = a.nx * a.ny;
     const PixelMap pm = map_pixel(a, unit, lane);
     const uint32_t pix = pm.valid ? pm.j * a.nx + pm.i : 0u;
-
-    // get_world_coordinates (main.cu:306-314) and pixel_size (main.cu:337)
-    const float height_world = 2.0f;
-    const float width_world = height_world * ((float)a.nx / (float)a.ny);
-    const float pix_w = width_world / (float)a.nx, pix_h = height_world / (float)a.ny;
-    // Camera::getRay constants (Camera.hpp:97-98,133-134)
-    const V3 cam_pos = ld3c(sc->cam.pos), cam_front = ld3c(sc->cam.front), cam_right = ld3c(sc->cam.right),
-             cam_up = ld3c(sc->cam.up);
-    const V3 eye = cam_pos - cam_front * (width_world * 0.5f * sc->cam.one_over_tan);
-    const uint32_t cam_type = sc->cam.type;
-    float ortho;
-    {
-        float aspect = height_world / width_world;
-        ortho = sc->cam.ortho_scale * (aspect > 1.0f ? aspect : 1.0f);
-    }
+    const CameraRays cam = load_camera(sc, a);
+    const float pix_w = cam.pix_w, pix_h = cam.pix_h;
     const uint32_t aa_iter = a.aa_iter > 4u ? 4u : a.aa_iter; // main.cu:233
     const float inv_ind = 1.0f / (float)a.ind_rays;    // main.cu:182
     // generator draws one diffuse hit consumes in LightList::calculateColor (AreaLight.hpp:342-343,495)
@@ -830,15 +1035,8 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
             t_cy = u2f(s[ST_T_CY * n_lp]);
         }
     }
-    // remap<float,true> (math_functions.hpp:31-45)
     float x_world, y_world;
-    {
-        float denom = (float)a.nx - 0.0f;
-        float es = -width_world * 0.5f, ee = width_world * 0.5f;
-        x_world = (denom == 0.0f) ? (float)pm.i : es + ((ee - es) / denom) * ((float)pm.i - 0.0f);
-        float denomy = (float)a.ny - 0.0f;
-        y_world = (denomy == 0.0f) ? (float)pm.j : 1.0f + ((-1.0f - 1.0f) / denomy) * ((float)pm.j - 0.0f);
-    }
+    cam.pixel_centre(a, pm.i, pm.j, x_world, y_world);
 
     // aa_color's task list (main.cu:230-304) lives in the state planes; it starts with the whole pixel
     uint32_t* aa_stack = w.state + (size_t)ST_AA * n_lp + lp; // entry e: planes 3e, 3e+1, 3e+2
@@ -871,15 +1069,29 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
     uint32_t cnt = 0; // result slots filled this round
     uint32_t cnt_shade = 0, cnt_expand = 0;
     const uint32_t quota = w.quota;
-    // Shade records are handed out to the wave in chunks of kWorkChunk consecutive indices, so the one
-    // global counter sees one atomic per chunk instead of one per step.
-    uint32_t chunk_base = 0, chunk_used = kWorkChunk; // wave-uniform
-    bool have_chunk = false;
+    WorkCursor wc = {0u, kWorkChunk, false};
+#ifdef CRT_TRACE_PROFILE // build with -DCRT_TRACE_PROFILE: every 37th wave prints its steps and the cycles per section
+    unsigned long long prof[4] = {0, 0, 0, 0}, prof_t = 0, prof_iters = 0;
+#define PROF_MARK(k)                                   \
+    do {                                               \
+        const unsigned long long now_ = clock64();    \
+        prof[k] += now_ - prof_t;                      \
+        prof_t = now_;                                 \
+    } while (0)
+    const unsigned long long wall0 = wall_clock64(), cyc0 = clock64();
+    prof_t = clock64();
+#else
+#define PROF_MARK(k)
+#endif
 
     for (;;) {
         const bool go = !done && !waiting && cnt < quota;
         if (!__any(go)) break;
-        bool emit = false; // a diffuse hit to record
+#ifdef CRT_TRACE_PROFILE
+        ++prof_iters;
+#endif
+        bool emit = false;      // a diffuse hit to record
+        bool want_coop = false; // COOP: the innermost frame's children are leaves
         V3 n_P = mk3(0, 0, 0), n_N = mk3(0, 0, 0), n_view = mk3(0, 0, 0);
         V4 n_att = V4{0, 0, 0, 0};
         uint32_t n_geom = 0, n_depth = 0;
@@ -919,17 +1131,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
                             rx = t_cx + ox * hx;
                             ry = t_cy + oy * hy;
                         }
-                        // Camera::getRay (Camera.hpp:86-144)
-                        V3 ro, rd;
-                        if (cam_type == CRT_CAM_ORTHOGRAPHIC) {
-                            ro = ((cam_right * rx) * ortho + (cam_up * ry) * ortho) + cam_pos;
-                            rd = ray_dir(cam_front);
-                        } else {
-                            ro = (cam_right * rx + cam_up * ry) + cam_pos;
-                            rd = ray_dir(ro - eye);
-                        }
-                        cur_o = ro;
-                        cur_d = rd;
+                        cam.ray(rx, ry, cur_o, cur_d);
                         cur_att = V4{1.0f, 1.0f, 1.0f, 1.0f};
                         cur_ref = a.ref_iter;
                         cur_depth = a.gl_iter;
@@ -949,162 +1151,88 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
                         waiting = t_level >= 2u; // whether to subdivide depends on the four colours (main.cu:283-300)
                     }
                 } else {
-                    // pop the next child of the innermost frame (children leave last-to-first)
                     uint32_t* f = w.frames + ((size_t)(nframes - 1u) * WF_FRAME_PLANES) * n_lp + lp;
-                    Rng rv;
-                    rv.v0 = f[(FR_RNG + 0) * n_lp];
-                    rv.v1 = f[(FR_RNG + 1) * n_lp];
-                    rv.v2 = f[(FR_RNG + 2) * n_lp];
-                    rv.v3 = f[(FR_RNG + 3) * n_lp];
-                    rv.v4 = f[(FR_RNG + 4) * n_lp];
-                    rv.d = f[(FR_RNG + 5) * n_lp];
-                    float r2 = rng_current_uniform(rv);
-                    rng_unstep(rv);
-                    float r1 = rng_current_uniform(rv);
-                    rng_unstep(rv);
-                    V3 hp = mk3(u2f(f[(FR_P + 0) * n_lp]), u2f(f[(FR_P + 1) * n_lp]), u2f(f[(FR_P + 2) * n_lp]));
-                    V3 hn = mk3(u2f(f[(FR_N + 0) * n_lp]), u2f(f[(FR_N + 1) * n_lp]), u2f(f[(FR_N + 2) * n_lp]));
-                    V4 patt = V4{u2f(f[(FR_ATT + 0) * n_lp]), u2f(f[(FR_ATT + 1) * n_lp]), u2f(f[(FR_ATT + 2) * n_lp]),
-                                 u2f(f[(FR_ATT + 3) * n_lp])};
-                    const uint32_t fgeom = f[FR_GEOM * n_lp];
-                    V4 pdiff = ld4c(sc->shade[fgeom].diffuse);
                     const uint32_t cdepth = f[FR_CHILD_DEPTH * n_lp];
-                    uint32_t rem = f[FR_REMAINING * n_lp] - 1u;
-                    if (rem == 0u) {
-                        --nframes;
+                    if (COOP && cdepth == 0u) {
+                        want_coop = true; // the wave expands these children together, below
                     } else {
-                        f[FR_REMAINING * n_lp] = rem;
-                        f[(FR_RNG + 0) * n_lp] = rv.v0;
-                        f[(FR_RNG + 1) * n_lp] = rv.v1;
-                        f[(FR_RNG + 2) * n_lp] = rv.v2;
-                        f[(FR_RNG + 3) * n_lp] = rv.v3;
-                        f[(FR_RNG + 4) * n_lp] = rv.v4;
-                        f[(FR_RNG + 5) * n_lp] = rv.d;
+                        // pop the next child of the innermost frame (children leave last-to-first); its two
+                        // draws are the last ones before the frame's generator state
+                        Rng rv;
+                        rv.v0 = f[(FR_RNG + 0) * n_lp];
+                        rv.v1 = f[(FR_RNG + 1) * n_lp];
+                        rv.v2 = f[(FR_RNG + 2) * n_lp];
+                        rv.v3 = f[(FR_RNG + 3) * n_lp];
+                        rv.v4 = f[(FR_RNG + 4) * n_lp];
+                        rv.d = f[(FR_RNG + 5) * n_lp];
+                        float r2 = rng_current_uniform(rv);
+                        rng_unstep(rv);
+                        float r1 = rng_current_uniform(rv);
+                        rng_unstep(rv);
+                        V3 hp = mk3(u2f(f[(FR_P + 0) * n_lp]), u2f(f[(FR_P + 1) * n_lp]), u2f(f[(FR_P + 2) * n_lp]));
+                        V3 hn = mk3(u2f(f[(FR_N + 0) * n_lp]), u2f(f[(FR_N + 1) * n_lp]), u2f(f[(FR_N + 2) * n_lp]));
+                        V4 patt = V4{u2f(f[(FR_ATT + 0) * n_lp]), u2f(f[(FR_ATT + 1) * n_lp]), u2f(f[(FR_ATT + 2) * n_lp]),
+                                     u2f(f[(FR_ATT + 3) * n_lp])};
+                        const uint32_t fgeom = f[FR_GEOM * n_lp];
+                        V4 pdiff = ld4c(sc->shade[fgeom].diffuse);
+                        uint32_t rem = f[FR_REMAINING * n_lp] - 1u;
+                        if (rem == 0u) {
+                            --nframes;
+                        } else {
+                            f[FR_REMAINING * n_lp] = rem;
+                            f[(FR_RNG + 0) * n_lp] = rv.v0;
+                            f[(FR_RNG + 1) * n_lp] = rv.v1;
+                            f[(FR_RNG + 2) * n_lp] = rv.v2;
+                            f[(FR_RNG + 3) * n_lp] = rv.v3;
+                            f[(FR_RNG + 4) * n_lp] = rv.v4;
+                            f[(FR_RNG + 5) * n_lp] = rv.d;
+                        }
+                        --on_stack;
+                        child_ray(hp, hn, patt, pdiff, r1, r2, inv_ind, cur_o, cur_d, cur_att);
+                        cur_ref = a.ref_iter;
+                        cur_depth = cdepth;
+                        cur_valid = true;
                     }
-                    --on_stack;
-                    // get_random_ray_values_in_hemisphere (main.cu:60-74)
-                    V3 Nx, Nz;
-                    surface_frame(hn, Nx, Nz);
-                    const float PI_2 = 6.28318530717958647692f;
-                    float sinTheta = 1.0f - r1 * r1;
-                    float phi = r2 * PI_2;
-                    float sp, cp;
-                    sincos_c(phi, sp, cp);
-                    float x = sinTheta * cp, z = sinTheta * sp;
-                    V3 wd = mk3(x * Nz.x + r1 * hn.x + z * Nx.x, x * Nz.y + r1 * hn.y + z * Nx.y,
-                                x * Nz.z + r1 * hn.z + z * Nx.z);
-                    cur_o = hp + wd * 0.01f;
-                    cur_d = wd;
-                    cur_att = ((pdiff * (2.0f * r1)) * patt) * inv_ind; // main.cu:186
-                    cur_ref = a.ref_iter;
-                    cur_depth = cdepth;
-                    cur_valid = true;
                 }
             }
+            PROF_MARK(0);
             if (cur_valid) {
                 // ---- pop (main.cu:132-147)
                 cur_valid = false;
                 if (cur_ref != 0u) {
-                    if (!eps_equal(len_sq(cur_d), 0.0f, kEpsSq)) ray_d = normalize3(cur_d);
-                    const V3 ro = cur_o;
-                    Hit h = closest_hit(sc, ro, ray_d, 0.0f);
-                    if (h.idx < 0) {
+                    const V3 view = neg(cur_d); // viewDir = -state.r_dir, the stored (un-normalised) direction
+                    const V4 att = cur_att;
+                    V3 P = mk3(0, 0, 0), N = mk3(0, 0, 0);
+                    uint32_t geom = 0;
+                    const uint32_t what = pop_ray(sc, cur_o, cur_d, cur_att, cur_ref, ray_d, P, N, geom);
+                    if (what == POP_MISS) {
                         // final_color += attenuation * Color::black() (main.cu:149-151)
-                        const V4 c = cur_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
+                        const V4 c = att * V4{0.0f, 0.0f, 0.0f, 1.0f};
                         w.contrib[(size_t)cnt * n_lp + lp] = make_float4(c.x, c.y, c.z, c.w);
                         ++cnt;
+                    } else if (what == POP_DIFFUSE) {
+                        emit = true;
+                        n_P = P;
+                        n_N = N;
+                        n_view = view;
+                        n_att = att;
+                        n_geom = geom;
+                        n_depth = cur_depth;
                     } else {
-                        V3 P, N;
-                        hit_point_normal(sc, h, ro, ray_d, P, N);
-                        if (h.mat_type == CRT_MAT_DIFFUSE) {
-                            emit = true;
-                            n_P = P;
-                            n_N = N;
-                            n_view = neg(cur_d); // viewDir = -state.r_dir, the stored (un-normalised) direction
-                            n_att = cur_att;
-                            n_geom = (uint32_t)h.idx;
-                            n_depth = cur_depth;
-                        } else if (h.mat_type == CRT_MAT_REFLECT) {
-                            // get_reflect_ray (main.cu:76-81)
-                            V3 I = normalize3(ray_d);
-                            V3 rdir = reflect3(I, normalize3(N));
-                            cur_o = P + rdir * 0.01f;
-                            cur_d = rdir;
-                            cur_att = cur_att * ld4c(sc->shade[h.idx].diffuse);
-                            cur_ref = cur_ref - 1u;
-                            cur_valid = true;
-                        } else {
-                            // get_refraction_ray (main.cu:83-108)
-                            bool front_face = dot3(ray_d, N) < 0.0f;
-                            V3 norm = front_face ? N : neg(N);
-                            float ratio = sc->shade[h.idx].refract_index / 1.0f;
-                            if (front_face) ratio = rcp_exact(ratio);
-                            V3 rdn = normalize3(ray_d);
-                            float cos_theta = __builtin_fminf(dot3(neg(rdn), norm), 1.0f);
-                            float sin_theta = rcp_exact(rsqrt_c(1.0f - cos_theta * cos_theta));
-                            bool cannot_refract = ratio * sin_theta > 1.0f; // reflectance(...) > 1 never holds
-                            V3 dir = cannot_refract ? reflect3(rdn, norm) : refract3(rdn, norm, ratio);
-                            cur_o = P + dir * 0.01f;
-                            cur_d = dir;
-                            cur_att = cur_att * ld4c(sc->shade[h.idx].diffuse);
-                            cur_ref = cur_ref - 1u;
-                            cur_valid = true;
-                        }
+                        cur_valid = true;
                     }
                 }
             }
         }
+        PROF_MARK(1);
         // ---- record the diffuse hits of this step (all lanes are here together)
         const uint64_t em = __ballot(emit);
         if (em != 0) {
-            const uint32_t n_emit = (uint32_t)__popcll(em);
-            const bool need_chunk = chunk_used + n_emit > kWorkChunk;
-            uint32_t new_base = 0;
-            if (need_chunk) {
-                if (lane == (uint32_t)__builtin_ctzll(em)) new_base = atomicAdd(&w.ctrs[WF_CTR_WORK], kWorkChunk);
-                new_base = (uint32_t)__builtin_amdgcn_readlane((int)new_base, __builtin_ctzll(em));
-            }
-            const uint32_t my_pos = chunk_used + lane_rank(em);
-            const uint32_t my_wi = my_pos < kWorkChunk ? chunk_base + my_pos : new_base + (my_pos - kWorkChunk);
-            if (need_chunk) {
-                chunk_base = new_base;
-                chunk_used = chunk_used + n_emit - kWorkChunk;
-                have_chunk = true;
-            } else {
-                chunk_used += n_emit;
-            }
+            const uint32_t my_wi = reserve_records(w, wc, em, lane);
             if (emit) {
-                const uint32_t wi = my_wi;
-                const uint32_t slot_k = cnt;
+                store_record(w, my_wi, n_P, n_N, n_view, n_att, n_geom, rng, (uint32_t)((size_t)cnt * n_lp + lp));
                 ++cnt;
                 ++cnt_shade;
-                if (wi < w.cap_work) {
-                    uint32_t* r = w.work + wi;
-                    const size_t cw = w.cap_work;
-                    r[(WK_P + 0) * cw] = f2u(n_P.x);
-                    r[(WK_P + 1) * cw] = f2u(n_P.y);
-                    r[(WK_P + 2) * cw] = f2u(n_P.z);
-                    r[(WK_N + 0) * cw] = f2u(n_N.x);
-                    r[(WK_N + 1) * cw] = f2u(n_N.y);
-                    r[(WK_N + 2) * cw] = f2u(n_N.z);
-                    r[(WK_V + 0) * cw] = f2u(n_view.x);
-                    r[(WK_V + 1) * cw] = f2u(n_view.y);
-                    r[(WK_V + 2) * cw] = f2u(n_view.z);
-                    r[(WK_ATT + 0) * cw] = f2u(n_att.x);
-                    r[(WK_ATT + 1) * cw] = f2u(n_att.y);
-                    r[(WK_ATT + 2) * cw] = f2u(n_att.z);
-                    r[(WK_ATT + 3) * cw] = f2u(n_att.w);
-                    r[WK_GEOM * cw] = n_geom;
-                    r[(WK_RNG + 0) * cw] = rng.v0;
-                    r[(WK_RNG + 1) * cw] = rng.v1;
-                    r[(WK_RNG + 2) * cw] = rng.v2;
-                    r[(WK_RNG + 3) * cw] = rng.v3;
-                    r[(WK_RNG + 4) * cw] = rng.v4;
-                    r[(WK_RNG + 5) * cw] = rng.d;
-                    r[WK_SLOT * cw] = (uint32_t)((size_t)slot_k * n_lp + lp);
-                } else {
-                    w.ctrs[WF_CTR_ERROR] = 1u;
-                }
                 // the light samples of this hit (drawn by the filter kernel from the recorded state)
                 if (skip_draws != 0u && skip_draws == w.jump_n[0]) rng_jump(rng, s_jump[0], skip_draws * 362437u);
                 else for (uint32_t k = 0; k < skip_draws; ++k) rng_step(rng);
@@ -1113,8 +1241,14 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
                     // The reference draws (r1,r2) for every child and pushes while its stack has room (main.cu:176-191).
                     uint32_t room = on_stack < CRT_RAY_STACK ? CRT_RAY_STACK - on_stack : 0u;
                     uint32_t accepted = a.ind_rays < room ? a.ind_rays : room;
-                    if (accepted != 0u && 2u * accepted == w.jump_n[1]) rng_jump(rng, s_jump[1], 2u * accepted * 362437u);
-                    else for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
+                    if (COOP && n_depth == 1u) {
+                        // leaf children: keep their draws where any lane of the wave can pick them up
+                        for (uint32_t k = 0; k < 2u * accepted; ++k) w.draws[(size_t)k * n_lp + lp] = rng_uniform(rng);
+                    } else if (accepted != 0u && 2u * accepted == w.jump_n[1]) {
+                        rng_jump(rng, s_jump[1], 2u * accepted * 362437u);
+                    } else {
+                        for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
+                    }
                     if (accepted > 0u) {
                         uint32_t* f = w.frames + ((size_t)nframes * WF_FRAME_PLANES) * n_lp + lp;
                         ++nframes;
@@ -1143,12 +1277,121 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
                 }
             }
         }
+        PROF_MARK(2);
+        if (COOP) {
+            // ---- leaf children: one lane per child ray, one owner (pixel) after the other.  Every child
+            // fills at most one result slot, so a batch of n <= quota - cnt children respects the quota.
+            uint64_t cm = __ballot(want_coop);
+            while (cm != 0) {
+                const int owner = __builtin_ctzll(cm);
+                cm &= cm - 1u;
+                const uint32_t o_lp = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)lp, owner);
+                const uint32_t o_nframes = (uint32_t)__builtin_amdgcn_readlane((int)nframes, owner);
+                const uint32_t o_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, owner);
+                Rng o_rng;
+                o_rng.v0 = (uint32_t)__builtin_amdgcn_readlane((int)rng.v0, owner);
+                o_rng.v1 = (uint32_t)__builtin_amdgcn_readlane((int)rng.v1, owner);
+                o_rng.v2 = (uint32_t)__builtin_amdgcn_readlane((int)rng.v2, owner);
+                o_rng.v3 = (uint32_t)__builtin_amdgcn_readlane((int)rng.v3, owner);
+                o_rng.v4 = (uint32_t)__builtin_amdgcn_readlane((int)rng.v4, owner);
+                o_rng.d = (uint32_t)__builtin_amdgcn_readlane((int)rng.d, owner);
+                V3 c_ray_d = mk3(u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(ray_d.x), owner)),
+                                 u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(ray_d.y), owner)),
+                                 u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(ray_d.z), owner)));
+                uint32_t* f = w.frames + ((size_t)(o_nframes - 1u) * WF_FRAME_PLANES) * n_lp + o_lp;
+                const uint32_t rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[FR_REMAINING * n_lp]);
+                const V3 hp = mk3(u2f(f[(FR_P + 0) * n_lp]), u2f(f[(FR_P + 1) * n_lp]), u2f(f[(FR_P + 2) * n_lp]));
+                const V3 hn = mk3(u2f(f[(FR_N + 0) * n_lp]), u2f(f[(FR_N + 1) * n_lp]), u2f(f[(FR_N + 2) * n_lp]));
+                const V4 patt = V4{u2f(f[(FR_ATT + 0) * n_lp]), u2f(f[(FR_ATT + 1) * n_lp]), u2f(f[(FR_ATT + 2) * n_lp]),
+                                   u2f(f[(FR_ATT + 3) * n_lp])};
+                const V4 pdiff = ld4c(sc->shade[f[FR_GEOM * n_lp]].diffuse);
+                uint32_t n = rem < quota - o_cnt ? rem : quota - o_cnt;
+                if (n > kCoopBatch) n = kCoopBatch;
+                const bool act = lane < n;
+                // lane j takes the j-th child to leave the stack: child rem-1-j, drawn as pair rem-1-j
+                const uint32_t child = act ? rem - 1u - lane : 0u;
+                const float r1 = w.draws[(size_t)(2u * child) * n_lp + o_lp];
+                const float r2 = w.draws[(size_t)(2u * child + 1u) * n_lp + o_lp];
+                V3 c_o, c_d;
+                V4 c_att;
+                child_ray(hp, hn, patt, pdiff, r1, r2, inv_ind, c_o, c_d, c_att);
+                uint32_t c_ref = a.ref_iter;
+                // the child's chain of mirror / glass bounces (main.cu:132-221 with gl_depth 0)
+                uint32_t outcome = 0; // 0 no slot (bounces used up), 1 miss, 2 diffuse hit
+                V3 c_P = mk3(0, 0, 0), c_N = mk3(0, 0, 0), c_view = mk3(0, 0, 0);
+                V4 r_att = V4{0, 0, 0, 0};
+                uint32_t c_geom = 0;
+                bool running = act;
+                while (__any(running)) {
+                    if (running) {
+                        running = false;
+                        if (c_ref != 0u) {
+                            c_view = neg(c_d);
+                            r_att = c_att;
+                            const uint32_t what = pop_ray(sc, c_o, c_d, c_att, c_ref, c_ray_d, c_P, c_N, c_geom);
+                            if (what == POP_MISS) outcome = 1u;
+                            else if (what == POP_DIFFUSE) outcome = 2u;
+                            else running = true;
+                        }
+                    }
+                }
+                const uint64_t m_slot = __ballot(outcome != 0u), m_rec = __ballot(outcome == 2u);
+                const uint32_t n_rec = (uint32_t)__popcll(m_rec);
+                const uint32_t slot_k = o_cnt + lane_rank(m_slot);
+                // generator state of the k-th diffuse hit: k shaded points' worth of draws after the owner's;
+                // lane n computes the state the owner continues with (k = n_rec)
+                const uint32_t my_k = outcome == 2u ? lane_rank(m_rec) : (lane == n ? n_rec : 0u);
+                Rng c_rng = o_rng;
+                {
+                    const uint32_t b = my_k & 7u, a8 = my_k >> 3;
+                    if (b != 0u) rng_jump(c_rng, w.coop_tabs + (size_t)(b - 1u) * kJumpWords, 0u);
+                    if (a8 != 0u) rng_jump(c_rng, w.coop_tabs + (size_t)(6u + a8) * kJumpWords, 0u);
+                    c_rng.d += my_k * skip_draws * 362437u;
+                }
+                if (outcome == 1u) {
+                    const V4 c = r_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
+                    w.contrib[(size_t)slot_k * n_lp + o_lp] = make_float4(c.x, c.y, c.z, c.w);
+                }
+                if (m_rec != 0) {
+                    const uint32_t my_wi = reserve_records(w, wc, m_rec, lane);
+                    if (outcome == 2u)
+                        store_record(w, my_wi, c_P, c_N, c_view, r_att, c_geom, c_rng, (uint32_t)((size_t)slot_k * n_lp + o_lp));
+                }
+                // ---- hand the results back to the owner
+                Rng nr;
+                nr.v0 = (uint32_t)__builtin_amdgcn_readlane((int)c_rng.v0, (int)n);
+                nr.v1 = (uint32_t)__builtin_amdgcn_readlane((int)c_rng.v1, (int)n);
+                nr.v2 = (uint32_t)__builtin_amdgcn_readlane((int)c_rng.v2, (int)n);
+                nr.v3 = (uint32_t)__builtin_amdgcn_readlane((int)c_rng.v3, (int)n);
+                nr.v4 = (uint32_t)__builtin_amdgcn_readlane((int)c_rng.v4, (int)n);
+                nr.d = (uint32_t)__builtin_amdgcn_readlane((int)c_rng.d, (int)n);
+                // the direction register keeps the last ray that had a usable direction (main.cu:138)
+                const V3 last_d = mk3(u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.x), (int)(n - 1u))),
+                                      u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.y), (int)(n - 1u))),
+                                      u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.z), (int)(n - 1u))));
+                if (lane == (uint32_t)owner) {
+                    cnt += (uint32_t)__popcll(m_slot);
+                    cnt_shade += n_rec;
+                    rng = nr;
+                    ray_d = last_d;
+                    on_stack -= n;
+                    if (rem == n) --nframes;
+                    else f[FR_REMAINING * n_lp] = rem - n;
+                }
+            }
+        }
+        PROF_MARK(3);
     }
 
+#ifdef CRT_TRACE_PROFILE
+    if (lane == 0 && unit % 37u == 0u)
+        printf("wave %u: %llu steps, %llu cycles, %llu ticks of 10 ns; next ray %llu, pop %llu, record %llu, cooperative %llu\n", unit,
+               prof_iters, clock64() - cyc0, wall_clock64() - wall0, prof[0], prof[1], prof[2], prof[3]);
+#endif
     // ---- the unused tail of the last chunk holds no record
-    if (have_chunk)
-        for (uint32_t k = chunk_used + lane; k < kWorkChunk; k += 64u)
-            if (chunk_base + k < w.cap_work) w.work[(size_t)WK_GEOM * w.cap_work + chunk_base + k] = kNoRecord;
+    if (wc.have)
+        for (uint32_t k = wc.used + lane; k < kWorkChunk; k += 64u)
+            if (wc.base + k < w.cap_work) w.work[(size_t)WK_GEOM * w.cap_work + wc.base + k] = kNoRecord;
 
     // ---- park the traversal
     w.slot_count[lp] = cnt;
@@ -1670,6 +1913,11 @@ void wavefront_release(WfWorkspace& ws) {
     (void)hipFree(ws.jump_dev);
     delete static_cast<EventTimer*>(ws.timer);
     (void)hipFree(ws.qcounts);
+    (void)hipFree(ws.draws);
+    (void)hipFree(ws.coop_tabs);
+    (void)hipFree(ws.unit_cost);
+    (void)hipFree(ws.unit_order);
+    (void)hipHostFree(ws.unit_host);
     const bool timing = ws.timing;
     ws = WfWorkspace();
     ws.timing = timing;
@@ -1702,7 +1950,7 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     const uint32_t quota = (uint32_t)want;
     const uint32_t levels = args.gl_iter ? args.gl_iter : 1u;
     if (ws.n_lp == n_lp && ws.quota >= quota && ws.gl_levels >= levels && ws.n_lights >= lights &&
-        ws.max_shadow_rays >= args.max_shadow_rays)
+        ws.max_shadow_rays >= args.max_shadow_rays && (!args.cooperative || ws.draws != nullptr))
         return hipSuccess;
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return e;
@@ -1735,6 +1983,13 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     grab((void**)&ws.queue, (size_t)3u * qcap * 4u);
     grab((void**)&ws.jump_dev, (size_t)2u * kJumpWords * 4u);
     grab((void**)&ws.qcounts, (size_t)kMaxFilterWaves * 4u);
+    grab((void**)&ws.unit_cost, (size_t)args.n_units * 4u);
+    grab((void**)&ws.unit_order, (size_t)args.n_units * 4u);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ws.unit_host, (size_t)2u * args.n_units * sizeof(uint32_t), hipHostMallocDefault);
+    if (args.cooperative) {
+        grab((void**)&ws.draws, (size_t)2u * CRT_RAY_STACK * n_lp * 4u);
+        grab((void**)&ws.coop_tabs, (size_t)kCoopTables * kJumpWords * 4u);
+    }
     if (e == hipSuccess) e = hipHostMalloc((void**)&ws.ctrs_host, WF_CTR_COUNT * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         wavefront_release(ws);
@@ -1790,6 +2045,11 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     w.jump_n[1] = ws.jump_n[1];
     w.qcounts = ws.qcounts;
     w.region_cap = 0;
+    w.draws = ws.draws;
+    w.coop_tabs = ws.coop_tabs;
+    w.unit_order = nullptr;
+    const bool coop = args.cooperative != 0u && args.gl_iter != 0u;
+    if (coop && (!ws.draws || !ws.coop_tabs)) return hipErrorInvalidValue; // wavefront_reserve was given other arguments
 
     // shadow rays per shade record, for sizing the filter batches
     // Filter launches: G persistent waves, each takes every G-th group of 64 records and owns a queue
@@ -1819,6 +2079,32 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         }
         w.jump_n[0] = ws.jump_n[0];
         w.jump_n[1] = ws.jump_n[1];
+        if (coop && ws.coop_n != want[0]) {
+            std::vector<uint32_t> tabs((size_t)kCoopTables * kJumpWords, 0u);
+            for (uint32_t t = 0; t < kCoopTables; ++t) {
+                const uint32_t points = t < 7u ? t + 1u : 8u * (t - 6u);
+                build_jump_table(points * want[0], tabs.data() + (size_t)t * kJumpWords);
+            }
+            e = hipMemcpyAsync(ws.coop_tabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return e;
+            ws.coop_n = want[0];
+        }
+    }
+    // Launch order of the trace kernel's units (most expensive first).  Worth a host round trip only when
+    // pixels take many steps and the launch is large enough to have late starters.
+    if (args.gl_iter != 0u && args.n_units > 1u) {
+        hipLaunchKernelGGL(wf_cost_kernel, dim3(args.n_units), dim3(64), 0, stream, w, ws.unit_cost);
+        e = hipMemcpyAsync(ws.unit_host, ws.unit_cost, (size_t)args.n_units * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        const uint32_t* cost = ws.unit_host; // non-negative floats: their bit patterns order like the values
+        uint32_t* order = ws.unit_host + args.n_units;
+        for (uint32_t u = 0; u < args.n_units; ++u) order[u] = u;
+        std::stable_sort(order, order + args.n_units, [cost](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+        e = hipMemcpyAsync(ws.unit_order, order, (size_t)args.n_units * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        w.unit_order = ws.unit_order;
     }
     uint32_t first = 1u;
     e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_COUNT * sizeof(uint32_t), stream);
@@ -1829,8 +2115,9 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         // slot tags default to TAG_ADD (0): the trace kernel stores only the rare end-of-call / end-of-pixel marks
         e = hipMemsetAsync(ws.tags, 0, (size_t)ws.quota * ws.n_lp, stream);
         if (e != hipSuccess) return e;
-        WF_TIMED(WF_K_TRACE, hipLaunchKernelGGL(wf_trace_kernel, dim3((args.n_units + kTraceWaves - 1u) / kTraceWaves),
-                                                dim3(64 * kTraceWaves), 0, stream, w, first));
+        const dim3 tgrid((args.n_units + kTraceWaves - 1u) / kTraceWaves), tblock(64 * kTraceWaves);
+        if (coop) WF_TIMED(WF_K_TRACE, hipLaunchKernelGGL(wf_trace_kernel<true>, tgrid, tblock, 0, stream, w, first));
+        else WF_TIMED(WF_K_TRACE, hipLaunchKernelGGL(wf_trace_kernel<false>, tgrid, tblock, 0, stream, w, first));
         e = hipMemcpyAsync(ws.ctrs_host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(stream);

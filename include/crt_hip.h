@@ -221,6 +221,19 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out);
 #define CRT_PIPELINE_PERSISTENT 1
 #define CRT_PIPELINE_WAVEFRONT 2
 int crt_set_pipeline(crt_ctx* ctx, int pipeline);
+/* How the wavefront pipeline's trace kernel walks the last level of the global-illumination tree
+ * (the ind_rays children of main.cu:176-191 that expand no further).  Same bits either way.
+ *   CRT_TRACE_PER_PIXEL    one lane per pixel pops the children one after the other (default)
+ *   CRT_TRACE_COOPERATIVE  the 64 lanes of a wave take one child ray each, one pixel after the other.
+ *                          Experimental: a pixel's dependent chain gets 10x shorter, but with 64 pixels
+ *                          per wave the batches of one wave still run back to back, and it measures 2x
+ *                          slower than per-pixel at every launch size tried
+ *   CRT_TRACE_AUTO         per-pixel
+ * No counterpart in the reference. */
+#define CRT_TRACE_AUTO 0
+#define CRT_TRACE_PER_PIXEL 1
+#define CRT_TRACE_COOPERATIVE 2
+int crt_set_trace_mode(crt_ctx* ctx, int mode);
 /* Per-kernel GPU time of the wavefront pipeline, measured with HIP events on the launch stream.
  * crt_set_timing(ctx, 1) starts (and zeroes) the accumulation, crt_get_kernel_times returns
  * milliseconds and launch counts in the order trace, filter, resolve, shade, sum.  A workspace

@@ -261,10 +261,12 @@ def test_full_size_gl1_properties(gpu_ctx, oracle):
 
 
 # ------------------------------------------------------------------ wavefront pipeline specifics
-def _wavefront_ctx():
+def _wavefront_ctx(trace_mode=None):
     from cudaraytracer_amd import abi
     ctx = crt.Context(0)
     ctx.set_pipeline(abi.CRT_PIPELINE_WAVEFRONT)
+    if trace_mode is not None:
+        ctx.set_trace_mode(trace_mode)
     return ctx
 
 
@@ -408,3 +410,67 @@ def test_random_scenes_persistent_kernel(oracle, seed):
         assert np.abs(fb - ref).max() <= 1e-5
     else:
         assert np.array_equal(fb, ref)
+
+
+# ------------------------------------------------------------------ cooperative expansion of the last GI level
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,aa,gl,ind,S,limit", [(24, 1, 1, 75, 50, None), (20, 1, 1, 130, 5, None), (12, 1, 2, 75, 3, None),
+                                                  (12, 0, 3, 5, 4, None), (16, 3, 1, 7, 4, None), (20, 1, 1, 75, 6, 1 << 20),
+                                                  (12, 2, 2, 9, 3, 1 << 20)])
+def test_cooperative_trace_matches_oracle(oracle, n, aa, gl, ind, S, limit):
+    """CRT_TRACE_COOPERATIVE: the children of the last GI level are traced one per lane.  Covers more
+    children than lanes (two batches), more than the reference's 128-entry ray stack accepts, deeper
+    trees (only the innermost level is cooperative), adaptive AA, and quotas that split a batch."""
+    from cudaraytracer_amd import abi
+    ctx = _wavefront_ctx(abi.CRT_TRACE_COOPERATIVE)
+    try:
+        if limit:
+            ctx.set_workspace_limit(limit)
+        st = crt.make_settings(nx=n, ny=n + 4, aa_iter=aa, gl_iter=gl, ind_rays=ind, shadowSamples=S)
+        fb, state = _gpu_render(ctx, crt.cornell_box(S), st, 21)
+        ref, _, ref_state = oracle.render(oracle.cornell(S), st, 21, want_state=True)
+        assert np.array_equal(state, ref_state), "sample trees diverged"
+        assert np.array_equal(fb, ref), f"{np.count_nonzero(fb != ref)} floats differ"
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [2, 9, 14, 17, 19, 23])
+def test_cooperative_trace_random_scenes(oracle, seed):
+    from scene_fuzz import random_scene
+    from cudaraytracer_amd import abi
+    st = crt.make_settings(nx=30, ny=22, aa_iter=1, gl_iter=1 + seed % 2, ind_rays=9, shadowSamples=4)
+    scene = random_scene(crt, seed, 4, wild=True)
+    ctx = _wavefront_ctx(abi.CRT_TRACE_COOPERATIVE)
+    try:
+        fb, state = _gpu_render(ctx, scene, st, seed)
+    finally:
+        ctx.close()
+    ref, _, ref_state = oracle.render(random_scene(oracle, seed, 4, wild=True), st, seed, want_state=True)
+    assert np.array_equal(state, ref_state)
+    if any(l.kind == abi.CRT_LIGHT_POINT for l in scene.lights):
+        assert np.abs(fb - ref).max() <= 1e-5
+    else:
+        assert np.array_equal(fb, ref)
+
+
+@pytest.mark.gpu
+def test_trace_modes_agree_on_a_shard():
+    """The per-pixel and the cooperative trace give the same compact shard buffer (720x720, rank 3 of 8)."""
+    from cudaraytracer_amd import abi
+    st = crt.make_settings(gl_iter=1, ind_rays=20, shadowSamples=8)
+    n = crt.shard_tiles_max(st.nx, st.ny, 8) * 64 * 4
+    out = []
+    for mode in (abi.CRT_TRACE_PER_PIXEL, abi.CRT_TRACE_COOPERATIVE):
+        ctx = _wavefront_ctx(mode)
+        try:
+            ctx.upload(crt.cornell_box(8))
+            ctx.rng_init(st.nx, st.ny, 5)
+            buf = ctx.fb_alloc(n)
+            ctx.render_shard(st, 3, 8, buf)
+            out.append((ctx.fb_download(buf, n), ctx.rng_export(st.nx, st.ny)))
+            ctx.fb_free(buf)
+        finally:
+            ctx.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
