@@ -783,15 +783,45 @@ DI void child_ray(V3 hp, V3 hn, V4 patt, V4 pdiff, float r1, float r2, float inv
     att = ((pdiff * (2.0f * r1)) * patt) * inv_ind;
 }
 
+// What the tree walk reads of a primitive by per-lane index, copied to LDS once per workgroup: a lone
+// wave spends most of a step waiting, and an LDS read returns in a quarter of the time of a cached
+// global one.  Row layout: vertex normals [0..11], Material::diffuse [12..15], refractIndex [16],
+// kind [17], sphere centre [18..20].
+constexpr uint32_t kPrimWords = 24;
+typedef float PrimTable[CRT_MAX_GEOMETRY][kPrimWords];
+DI void fill_prim_table(ScenePtr sc, PrimTable& t, uint32_t tid, uint32_t nthreads) {
+    const uint32_t n = sc->n_geom;
+    for (uint32_t k = tid; k < n * kPrimWords; k += nthreads) {
+        const uint32_t i = k / kPrimWords, wd = k % kPrimWords;
+        float v = 0.0f;
+        if (wd < 12u) v = sc->shade[i].n[wd / 3u][wd % 3u];
+        else if (wd < 16u) v = sc->shade[i].diffuse[wd - 12u];
+        else if (wd == 16u) v = sc->shade[i].refract_index;
+        else if (wd == 17u) v = u2f(sc->hot[i].kind);
+        else if (wd < 21u) v = sc->hot[i].o[wd - 18u];
+        t[i][wd] = v;
+    }
+}
+
 // One pop of color()'s loop (main.cu:132-221) for a ray with bounces left, without the shading.
 enum : uint32_t { POP_MISS = 0, POP_DIFFUSE = 1, POP_BOUNCE = 2 };
-DI uint32_t pop_ray(ScenePtr sc, V3& cur_o, V3& cur_d, V4& cur_att, uint32_t& cur_ref, V3& ray_d, V3& P, V3& N,
-                    uint32_t& geom) {
+DI uint32_t pop_ray(ScenePtr sc, const PrimTable& prim, V3& cur_o, V3& cur_d, V4& cur_att, uint32_t& cur_ref, V3& ray_d,
+                    V3& P, V3& N, uint32_t& geom) {
     if (!eps_equal(len_sq(cur_d), 0.0f, kEpsSq)) ray_d = normalize3(cur_d);
     const V3 ro = cur_o;
     Hit h = closest_hit(sc, ro, ray_d, 0.0f);
     if (h.idx < 0) return POP_MISS;
-    hit_point_normal(sc, h, ro, ray_d, P, N);
+    const float* pr = prim[h.idx];
+    // hit point and shading normal (Sphere.hpp:102-107, Quad.hpp:299-325)
+    P = ro + ray_d * h.t;
+    if (f2u(pr[17]) == CRT_GEOM_SPHERE) {
+        N = normalize3(P - mk3(pr[18], pr[19], pr[20]));
+    } else {
+        const float u = h.u, v = h.v;
+        const float l0 = (1 - u) * (1 - v), l1 = u * (1 - v), l2 = u * v, l3 = (1 - u) * v;
+        N = V3{l0 * pr[0] + l1 * pr[3] + l2 * pr[6] + l3 * pr[9], l0 * pr[1] + l1 * pr[4] + l2 * pr[7] + l3 * pr[10],
+               l0 * pr[2] + l1 * pr[5] + l2 * pr[8] + l3 * pr[11]};
+    }
     geom = (uint32_t)h.idx;
     if (h.mat_type == CRT_MAT_DIFFUSE) return POP_DIFFUSE;
     if (h.mat_type == CRT_MAT_REFLECT) {
@@ -804,7 +834,7 @@ DI uint32_t pop_ray(ScenePtr sc, V3& cur_o, V3& cur_d, V4& cur_att, uint32_t& cu
         // get_refraction_ray (main.cu:83-108)
         bool front_face = dot3(ray_d, N) < 0.0f;
         V3 norm = front_face ? N : neg(N);
-        float ratio = sc->shade[h.idx].refract_index / 1.0f;
+        float ratio = pr[16] / 1.0f;
         if (front_face) ratio = rcp_exact(ratio);
         V3 rdn = normalize3(ray_d);
         float cos_theta = __builtin_fminf(dot3(neg(rdn), norm), 1.0f);
@@ -814,7 +844,7 @@ DI uint32_t pop_ray(ScenePtr sc, V3& cur_o, V3& cur_d, V4& cur_att, uint32_t& cu
         cur_o = P + dir * 0.01f;
         cur_d = dir;
     }
-    cur_att = cur_att * ld4c(sc->shade[h.idx].diffuse);
+    cur_att = cur_att * V4{pr[12], pr[13], pr[14], pr[15]};
     cur_ref = cur_ref - 1u;
     return POP_BOUNCE;
 }
@@ -927,6 +957,9 @@ __global__ void __launch_bounds__(64) wf_cost_kernel(WfArgs w, uint32_t* unit_co
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
     const uint32_t lane = threadIdx.x, unit = blockIdx.x;
+    __shared__ PrimTable s_prim;
+    fill_prim_table(sc, s_prim, lane, 64u);
+    __syncthreads();
     const PixelMap pm = map_pixel(a, unit, lane);
     const CameraRays cam = load_camera(sc, a);
     float cost = 0.0f;
@@ -939,7 +972,7 @@ __global__ void __launch_bounds__(64) wf_cost_kernel(WfArgs w, uint32_t* unit_co
         uint32_t ref = a.ref_iter, geom = 0, what = POP_MISS;
         float steps = 0.0f;
         while (ref != 0u) {
-            what = pop_ray(sc, o, d, att, ref, ray_d, P, N, geom);
+            what = pop_ray(sc, s_prim, o, d, att, ref, ray_d, P, N, geom);
             steps += 1.0f;
             if (what != POP_BOUNCE) break;
         }
@@ -978,8 +1011,10 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
     __shared__ __attribute__((aligned(16))) uint32_t s_jump[2][kJumpWords];
+    __shared__ PrimTable s_prim;
     for (uint32_t k = threadIdx.x; k < 2u * kJumpWords; k += 64u * kTraceWaves)
         s_jump[k / kJumpWords][k % kJumpWords] = w.jump_tabs[k];
+    fill_prim_table(sc, s_prim, threadIdx.x, 64u * kTraceWaves);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t launch_slot = blockIdx.x * kTraceWaves + (threadIdx.x >> 6);
@@ -1173,8 +1208,8 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                         V3 hn = mk3(u2f(f[(FR_N + 0) * n_lp]), u2f(f[(FR_N + 1) * n_lp]), u2f(f[(FR_N + 2) * n_lp]));
                         V4 patt = V4{u2f(f[(FR_ATT + 0) * n_lp]), u2f(f[(FR_ATT + 1) * n_lp]), u2f(f[(FR_ATT + 2) * n_lp]),
                                      u2f(f[(FR_ATT + 3) * n_lp])};
-                        const uint32_t fgeom = f[FR_GEOM * n_lp];
-                        V4 pdiff = ld4c(sc->shade[fgeom].diffuse);
+                        const float* fpr = s_prim[f[FR_GEOM * n_lp]];
+                        V4 pdiff = V4{fpr[12], fpr[13], fpr[14], fpr[15]};
                         uint32_t rem = f[FR_REMAINING * n_lp] - 1u;
                         if (rem == 0u) {
                             --nframes;
@@ -1204,7 +1239,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                     const V4 att = cur_att;
                     V3 P = mk3(0, 0, 0), N = mk3(0, 0, 0);
                     uint32_t geom = 0;
-                    const uint32_t what = pop_ray(sc, cur_o, cur_d, cur_att, cur_ref, ray_d, P, N, geom);
+                    const uint32_t what = pop_ray(sc, s_prim, cur_o, cur_d, cur_att, cur_ref, ray_d, P, N, geom);
                     if (what == POP_MISS) {
                         // final_color += attenuation * Color::black() (main.cu:149-151)
                         const V4 c = att * V4{0.0f, 0.0f, 0.0f, 1.0f};
@@ -1304,7 +1339,8 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                 const V3 hn = mk3(u2f(f[(FR_N + 0) * n_lp]), u2f(f[(FR_N + 1) * n_lp]), u2f(f[(FR_N + 2) * n_lp]));
                 const V4 patt = V4{u2f(f[(FR_ATT + 0) * n_lp]), u2f(f[(FR_ATT + 1) * n_lp]), u2f(f[(FR_ATT + 2) * n_lp]),
                                    u2f(f[(FR_ATT + 3) * n_lp])};
-                const V4 pdiff = ld4c(sc->shade[f[FR_GEOM * n_lp]].diffuse);
+                const float* fpr = s_prim[f[FR_GEOM * n_lp]];
+                const V4 pdiff = V4{fpr[12], fpr[13], fpr[14], fpr[15]};
                 uint32_t n = rem < quota - o_cnt ? rem : quota - o_cnt;
                 if (n > kCoopBatch) n = kCoopBatch;
                 const bool act = lane < n;
@@ -1328,7 +1364,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                         if (c_ref != 0u) {
                             c_view = neg(c_d);
                             r_att = c_att;
-                            const uint32_t what = pop_ray(sc, c_o, c_d, c_att, c_ref, c_ray_d, c_P, c_N, c_geom);
+                            const uint32_t what = pop_ray(sc, s_prim, c_o, c_d, c_att, c_ref, c_ray_d, c_P, c_N, c_geom);
                             if (what == POP_MISS) outcome = 1u;
                             else if (what == POP_DIFFUSE) outcome = 2u;
                             else running = true;
