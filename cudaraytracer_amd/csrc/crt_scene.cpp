@@ -241,6 +241,7 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
         if (in->lights[l].kind == CRT_LIGHT_AREA)
             for (int v = 0; v < 4; ++v)
                 for (int k = 0; k < 3; ++k) grow(out->lights[l].pts[v][k]);
+    bool hull_ok[CRT_MAX_GEOMETRY] = {}; // quads whose accepted (u,v) region is known to lie within their vertices' hull
     for (uint32_t i = 0; i < CRT_MAX_GEOMETRY; ++i) {
         DevGeomBox& b = out->box[i];
         for (int k = 0; k < 3; ++k) {
@@ -281,6 +282,7 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
             const double skew = fabs((double)uvq.kg[0]) + fabs((double)uvq.kg[1]);
             if (!(skew * span <= 1e-5 * fabs((double)uvq.nor_id))) continue;
         }
+        hull_ok[i] = true;
         const DevGeomHot& h = out->hot[i];
         const double nlen = sqrt((double)h.n[0] * h.n[0] + (double)h.n[1] * h.n[1] + (double)h.n[2] * h.n[2]);
         if (!(nlen > 1e-12) || !(nlen < 1e12)) continue;
@@ -354,7 +356,7 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
                 for (int k = 0; k < 3; ++k) c2 += ((double)o.center[k] - sg.center[k]) * ((double)o.center[k] - sg.center[k]);
                 const double gap = sqrt(c2) - fabs((double)o.radius);
                 d2 = gap > 0.0 ? gap * gap : 0.0;
-            } else {
+            } else if (hull_ok[j]) {
                 for (int k = 0; k < 3; ++k) {
                     double lo = INFINITY, hi = -INFINITY;
                     for (int v = 0; v < 4; ++v) {
@@ -365,7 +367,8 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
                     const double gap = c < lo ? lo - c : (c > hi ? c - hi : 0.0);
                     d2 += gap * gap;
                 }
-            }
+            } // any other quad stays a candidate: the reference's (u,v) solve can accept points outside the
+              // hull of its vertices (linear branch with skew, quadratic branch with a tiny k2)
             if (j == g || !(d2 > reach * reach)) mask |= 1ull << j;
         }
         out->interior_lo[g] = (uint32_t)mask;

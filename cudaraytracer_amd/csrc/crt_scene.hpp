@@ -124,6 +124,8 @@ struct alignas(64) DevScene {
     // cull_thr = +inf where no such statement holds (spheres, quads the light straddles or touches).
     // For a sphere g: the primitives that come within its ball (itself included).  A ray that starts
     // inside the ball leaves it after at most 2r, so nothing outside this set can be its closest hit.
+    // A quad is judged by the hull of its vertices only when it is a true parallelogram; any other quad
+    // is always in the set, because the reference's (u,v) solve can accept points outside that hull.
     // All ones for quads.
     uint32_t interior_lo[CRT_MAX_GEOMETRY], interior_hi[CRT_MAX_GEOMETRY];
     // 1 when quad g is parallel to the plane of area light l (nor.D is then the same for every sample)

@@ -1614,6 +1614,23 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
                     covered = k.sure_opaque && !k.maybe_glass;
                     unresolved = !covered && (k.maybe_any || k.sure_opaque);
                 }
+#ifdef CRT_SHADE_TRACE
+                if (act) {
+                    const uint32_t lp_ = r[WK_SLOT * cw] % w.n_lp;
+                    const PixelMap pm_ = map_pixel(w.r, lp_ / 64u, lp_ % 64u);
+                    if (pm_.valid && pm_.j * w.r.nx + pm_.i == (uint32_t)(CRT_SHADE_TRACE)) {
+                        V3 o_, d_;
+                        float x_;
+                        shadow_ray(lc, P, u, v, o_, d_, x_);
+                        const Hit h_ = closest_hit(sc, o_, d_, x_);
+                        bool cov_ = h_.idx >= 0;
+                        if (cov_ && h_.mat_type == CRT_MAT_REFRACTIVE) cov_ = covered_through_glass(sc, L, o_, d_, h_);
+                        printf("gpu:   P=(%.9g %.9g %.9g) light %u sample %u u=%.9g v=%.9g dist %.9g class %u filter %s, exact: hit %d t=%.9g covered %d\n",
+                               P.x, P.y, P.z, li, s, u, v, x_, rec_class, unresolved ? "undecided" : (covered ? "blocked" : "free"), h_.idx, h_.t,
+                               (int)cov_);
+                    }
+                }
+#endif
                 if (act && !unresolved) {
                     V3 o, d;
                     float x;
@@ -1782,6 +1799,15 @@ __global__ void __launch_bounds__(64, 4) wf_shade_kernel(WfArgs w, uint32_t w_be
             const uint32_t S = L->shadow_samples;
             const uint32_t shadowed = w.shadow_cnt[(size_t)li * cw + wi];
             float visibility = 1.0f - ((float)shadowed / (float)S); // AreaLight.hpp:527
+#ifdef CRT_SHADE_TRACE // build with -DCRT_SHADE_TRACE=<pixel index j*nx+i>: the shadow counts of that pixel's shaded points
+            {
+                const uint32_t lp = slot % w.n_lp;
+                const PixelMap pm = map_pixel(w.r, lp / 64u, lp % 64u);
+                if (pm.valid && pm.j * w.r.nx + pm.i == (uint32_t)(CRT_SHADE_TRACE))
+                    printf("gpu: P=(%.9g %.9g %.9g) light at (%.9g %.9g %.9g): %u of %u shadow rays covered\n", P.x, P.y, P.z,
+                           L->pos[0], L->pos[1], L->pos[2], shadowed, S);
+            }
+#endif
             direct = direct + area_light_shade(w.r.ltc, L, gs, P, N, view, visibility);
         }
     }

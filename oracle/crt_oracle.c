@@ -31,6 +31,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -423,6 +424,7 @@ static int point_on_ray(const ray_t* ray, v3 point) {
 }
 
 /* Light::_isCovered, Light.hpp:35-86 */
+static int orc_trace_enabled(void);
 static int is_covered(const ctx_t* cx, const crt_light* L, const ray_t* ray_in, unsigned iterations) {
     hit_t hit = hit_default();
     ray_t r = *ray_in;
@@ -435,6 +437,9 @@ static int is_covered(const ctx_t* cx, const crt_light* L, const ray_t* ray_in, 
         } else {
             if (iterations == 0) return 0;
             int front_face = v3_dot(r.d, hit.n) < 0.0f;
+            if (orc_trace_enabled())
+                fprintf(stderr, "oracle:     glass walk %u: from (%.9g %.9g %.9g) hit at (%.9g %.9g %.9g) t=%.9g front %d\n", i, r.o.x,
+                        r.o.y, r.o.z, hit.p.x, hit.p.y, hit.p.z, hit.t, front_face);
             v3 norm = front_face ? hit.n : v3_neg(hit.n);
             float ratio = hit.mat->refractIndex / 1.0f;
             if (front_face) ratio = fdiv(1.0f, ratio);
@@ -473,6 +478,14 @@ static v3 area_random_point(const ctx_t* cx, const crt_light* L) {
     }
 }
 
+/* Debugging aid: with ORC_TRACE set in the environment every shaded point's shadow count is printed
+ * (render one pixel with the region arguments of orc_render). */
+static int orc_trace_enabled(void) {
+    static int state = -1;
+    if (state < 0) state = getenv("ORC_TRACE") != NULL;
+    return state;
+}
+
 /* AreaLight::_calculateVisibility, AreaLight.hpp:484-529 */
 static float area_visibility(const ctx_t* cx, const crt_light* L, v3 position) {
     unsigned shadowed = 0;
@@ -482,8 +495,14 @@ static float area_visibility(const ctx_t* cx, const crt_light* L, v3 position) {
         float dist = v3_length(dir);
         if (!eps_equal(dist, 0.0f, EPS)) dir = v3_normalize(dir);
         ray_t ray = ray_make3(v3_add(position, v3_scale(dir, 0.01f)), dir, dist);
-        if (is_covered(cx, L, &ray, 10u)) ++shadowed;
+        const int covered = is_covered(cx, L, &ray, 10u);
+        if (covered) ++shadowed;
+        if (orc_trace_enabled())
+            fprintf(stderr, "oracle:   sample %u X=(%.9g %.9g %.9g) dist %.9g covered %d\n", i, sample.x, sample.y, sample.z, dist, covered);
     }
+    if (orc_trace_enabled())
+        fprintf(stderr, "oracle: P=(%.9g %.9g %.9g) light at (%.9g %.9g %.9g): %u of %u shadow rays covered\n", position.x,
+                position.y, position.z, L->pos[0], L->pos[1], L->pos[2], shadowed, L->shadowSamples);
     return 1.0f - fdiv((float)shadowed, (float)L->shadowSamples);
 }
 

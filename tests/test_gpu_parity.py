@@ -474,3 +474,19 @@ def test_trace_modes_agree_on_a_shard():
         finally:
             ctx.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,aa", [(300918, 0), (301969, 4)])
+def test_glass_walk_inside_spheres_with_untrusted_quads(oracle, gpu_ctx, seed, aa):
+    """Scaled scenes full of glass, found by tools/fuzz_gpu.py: a shadow ray inside a glass sphere meets a glass
+    quad whose (u,v) solve takes the quadratic branch with k2 close to zero (a parallelogram after rounding of
+    its scaled vertices) and accepts a point outside the hull of its vertices.  The shortcut that looks only at
+    primitives reaching into the sphere must not drop such a quad."""
+    from scene_fuzz import random_scene
+    S = 3 + seed % 7
+    st = crt.make_settings(nx=36, ny=28, aa_iter=aa, gl_iter=1, ind_rays=5, shadowSamples=S)
+    fb, state = _gpu_render(gpu_ctx, random_scene(crt, seed, S, wild=True), st, seed)
+    ref, _, ref_state = oracle.render(random_scene(oracle, seed, S, wild=True), st, seed, want_state=True)
+    assert np.array_equal(state, ref_state)
+    assert np.array_equal(fb, ref), f"{np.count_nonzero(fb != ref)} floats differ, max {np.abs(fb - ref).max()}"
