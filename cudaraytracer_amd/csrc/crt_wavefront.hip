@@ -82,7 +82,7 @@ struct WfArgs {
     uint32_t region_cap;  // queue entries per filter wave
     const uint32_t* unit_order; // trace: launch slot -> work unit, most expensive first; null = identity
     float* draws;              // cooperative trace: [2 * CRT_RAY_STACK][n_lp] child draws of the innermost leaf node
-    const uint32_t* coop_tabs; // cooperative trace: 14 rng_jump tables in device memory (kCoopTables)
+    const uint32_t* coop_tabs; // cooperative trace: kCoopTables more rng_jump tables (4 and 16 shaded points' worth of draws)
 };
 
 DI float u2f(uint32_t x) { return __uint_as_float(x); }
@@ -763,8 +763,13 @@ DI uint32_t record_light_class(ScenePtr sc, uint32_t li, const LightF& lf, V3 P)
 constexpr uint32_t kTraceWaves = 4; // waves per trace workgroup (they share the generator jump tables in LDS)
 // Cooperative expansion handles at most 63 children at a time, so that a 64th lane can compute the
 // generator state the pixel continues with; the k-th diffuse hit of a batch starts k shaded points'
-// worth of draws further on, k = 8a + b: tables 0..6 jump b = 1..7 points, tables 7..13 jump 8a points.
-constexpr uint32_t kCoopBatch = 63, kCoopTables = 14;
+// worth of draws further on, k = 16c + 4b + a: a jumps of one point, b of four, c of sixteen, with the
+// three tables in LDS (at most nine jumps; tables in device memory made every lookup a cache miss).
+constexpr uint32_t kCoopBatch = 63, kCoopTables = 2;
+// In the cooperative kernel a wave owns 8 of its unit's 64 pixels (one row of the tile) and kCoopSplit
+// waves share the unit: the batches of one wave run back to back, so fewer owners per wave means more
+// of them in flight.
+constexpr uint32_t kCoopSplit = 8;
 
 // Children of the innermost frame leave last-to-first (main.cu:176-191 pushes, :132 pops):
 // get_random_ray_values_in_hemisphere (main.cu:60-74) and the child's attenuation (main.cu:186).
@@ -1010,16 +1015,24 @@ template <bool COOP>
 __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kernel(WfArgs w, uint32_t first) {
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
-    __shared__ __attribute__((aligned(16))) uint32_t s_jump[2][kJumpWords];
+    // [0] one shaded point's draws; per-pixel kernel: [1] the 2 ind_rays child draws; cooperative kernel:
+    // [1], [2] four and sixteen shaded points' draws (it steps or, for inner levels, jumps through a
+    // table in device memory over the child draws)
+    __shared__ __attribute__((aligned(16))) uint32_t s_jump[COOP ? 3 : 2][kJumpWords];
     __shared__ PrimTable s_prim;
-    for (uint32_t k = threadIdx.x; k < 2u * kJumpWords; k += 64u * kTraceWaves)
+    for (uint32_t k = threadIdx.x; k < (COOP ? 1u : 2u) * kJumpWords; k += 64u * kTraceWaves)
         s_jump[k / kJumpWords][k % kJumpWords] = w.jump_tabs[k];
+    if (COOP)
+        for (uint32_t k = threadIdx.x; k < kCoopTables * kJumpWords; k += 64u * kTraceWaves)
+            s_jump[1u + k / kJumpWords][k % kJumpWords] = w.coop_tabs[k];
     fill_prim_table(sc, s_prim, threadIdx.x, 64u * kTraceWaves);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t launch_slot = blockIdx.x * kTraceWaves + (threadIdx.x >> 6);
+    const uint32_t wave_slot = blockIdx.x * kTraceWaves + (threadIdx.x >> 6);
+    const uint32_t launch_slot = COOP ? wave_slot / kCoopSplit : wave_slot;
     if (launch_slot >= a.n_units) return;
     const uint32_t unit = w.unit_order ? w.unit_order[launch_slot] : launch_slot; // most expensive units first
+    const bool own = !COOP || (lane >> 3) == wave_slot % kCoopSplit; // the pixels this wave walks
     const size_t n_lp = w.n_lp;
     const size_t lp = (size_t)unit * 64u + lane;
     const uint32_t npix = a.nx * a.ny;
@@ -1038,8 +1051,8 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
 
     // ---- traversal state
     uint32_t ctl = 0;
-    if (!first) ctl = w.state[ST_CTL * n_lp + lp];
-    bool done = !pm.valid || (ctl & 1u);
+    if (!first && own) ctl = w.state[ST_CTL * n_lp + lp];
+    bool done = !pm.valid || !own || (ctl & 1u);
     const bool live_at_entry = !done;
     bool color_active = (ctl >> 1) & 1u, cur_valid = (ctl >> 2) & 1u;
     bool task_active = (ctl >> 3) & 1u, waiting = (ctl >> 4) & 1u;
@@ -1106,7 +1119,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
     const uint32_t quota = w.quota;
     WorkCursor wc = {0u, kWorkChunk, false};
 #ifdef CRT_TRACE_PROFILE // build with -DCRT_TRACE_PROFILE: every 37th wave prints its steps and the cycles per section
-    unsigned long long prof[4] = {0, 0, 0, 0}, prof_t = 0, prof_iters = 0;
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = 0, prof_iters = 0;
 #define PROF_MARK(k)                                   \
     do {                                               \
         const unsigned long long now_ = clock64();    \
@@ -1280,7 +1293,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                         // leaf children: keep their draws where any lane of the wave can pick them up
                         for (uint32_t k = 0; k < 2u * accepted; ++k) w.draws[(size_t)k * n_lp + lp] = rng_uniform(rng);
                     } else if (accepted != 0u && 2u * accepted == w.jump_n[1]) {
-                        rng_jump(rng, s_jump[1], 2u * accepted * 362437u);
+                        rng_jump(rng, COOP ? w.jump_tabs + kJumpWords : s_jump[1], 2u * accepted * 362437u);
                     } else {
                         for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
                     }
@@ -1352,6 +1365,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                 V4 c_att;
                 child_ray(hp, hn, patt, pdiff, r1, r2, inv_ind, c_o, c_d, c_att);
                 uint32_t c_ref = a.ref_iter;
+                PROF_MARK(4);
                 // the child's chain of mirror / glass bounces (main.cu:132-221 with gl_depth 0)
                 uint32_t outcome = 0; // 0 no slot (bounces used up), 1 miss, 2 diffuse hit
                 V3 c_P = mk3(0, 0, 0), c_N = mk3(0, 0, 0), c_view = mk3(0, 0, 0);
@@ -1371,6 +1385,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                         }
                     }
                 }
+                PROF_MARK(5);
                 const uint64_t m_slot = __ballot(outcome != 0u), m_rec = __ballot(outcome == 2u);
                 const uint32_t n_rec = (uint32_t)__popcll(m_rec);
                 const uint32_t slot_k = o_cnt + lane_rank(m_slot);
@@ -1379,11 +1394,14 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                 const uint32_t my_k = outcome == 2u ? lane_rank(m_rec) : (lane == n ? n_rec : 0u);
                 Rng c_rng = o_rng;
                 {
-                    const uint32_t b = my_k & 7u, a8 = my_k >> 3;
-                    if (b != 0u) rng_jump(c_rng, w.coop_tabs + (size_t)(b - 1u) * kJumpWords, 0u);
-                    if (a8 != 0u) rng_jump(c_rng, w.coop_tabs + (size_t)(6u + a8) * kJumpWords, 0u);
+                    for (uint32_t level = 0; level < 3u && skip_draws != 0u; ++level) { // no light draws: no tables, nothing to skip
+                        const uint32_t digit = (my_k >> (2u * level)) & 3u;
+                        for (uint32_t r = 0; __any(digit > r); ++r)
+                            if (digit > r) rng_jump(c_rng, s_jump[COOP ? level : 0u], 0u);
+                    }
                     c_rng.d += my_k * skip_draws * 362437u;
                 }
+                PROF_MARK(6);
                 if (outcome == 1u) {
                     const V4 c = r_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
                     w.contrib[(size_t)slot_k * n_lp + o_lp] = make_float4(c.x, c.y, c.z, c.w);
@@ -1414,6 +1432,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                     if (rem == n) --nframes;
                     else f[FR_REMAINING * n_lp] = rem - n;
                 }
+                PROF_MARK(7);
             }
         }
         PROF_MARK(3);
@@ -1421,8 +1440,9 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
 
 #ifdef CRT_TRACE_PROFILE
     if (lane == 0 && unit % 37u == 0u)
-        printf("wave %u: %llu steps, %llu cycles, %llu ticks of 10 ns; next ray %llu, pop %llu, record %llu, cooperative %llu\n", unit,
-               prof_iters, clock64() - cyc0, wall_clock64() - wall0, prof[0], prof[1], prof[2], prof[3]);
+        printf("wave %u: %llu steps, %llu cycles, %llu ticks of 10 ns; next ray %llu, pop %llu, record %llu, cooperative %llu "
+               "(children %llu, chains %llu, jumps %llu, results %llu)\n", unit, prof_iters, clock64() - cyc0, wall_clock64() - wall0,
+               prof[0], prof[1], prof[2], prof[3] + prof[4] + prof[5] + prof[6] + prof[7], prof[4], prof[5], prof[6], prof[7]);
 #endif
     // ---- the unused tail of the last chunk holds no record
     if (wc.have)
@@ -1430,7 +1450,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
             if (wc.base + k < w.cap_work) w.work[(size_t)WK_GEOM * w.cap_work + wc.base + k] = kNoRecord;
 
     // ---- park the traversal
-    w.slot_count[lp] = cnt;
+    if (own) w.slot_count[lp] = cnt;
     if (live_at_entry) {
         a.rng[0 * (size_t)npix + pix] = rng.v0;
         a.rng[1 * (size_t)npix + pix] = rng.v1;
@@ -1463,7 +1483,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
             s[ST_T_CX * n_lp] = f2u(t_cx);
             s[ST_T_CY * n_lp] = f2u(t_cy);
         }
-    } else if (first) {
+    } else if (first && own) {
         w.state[ST_CTL * n_lp + lp] = 1u; // pixel slots outside the image never run
     }
     const uint64_t alive = __ballot(!done);
@@ -2005,8 +2025,9 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     uint64_t quota_max = budget_bytes / (per_slot * n_lp);
     if (quota_max < 16u) quota_max = 16u;
     if (want > quota_max) want = quota_max;
-    if ((want + 2u * kWorkChunk / 64u + 1u) * n_lp >= (1ull << 28)) { // record index and light share one word
-        want = ((1ull << 28) - 1u) / n_lp - 2u * kWorkChunk / 64u - 1u;
+    const uint64_t chunk_slack = (args.cooperative ? kCoopSplit : 1u) * 2u * kWorkChunk / 64u; // partly used chunks, per pixel slot
+    if ((want + chunk_slack + 1u) * n_lp >= (1ull << 28)) { // record index and light share one word
+        want = ((1ull << 28) - 1u) / n_lp - chunk_slack - 1u;
         if (want < 8u) return hipErrorOutOfMemory; // more than 2^25 pixel slots in one launch
     }
     const uint32_t quota = (uint32_t)want;
@@ -2018,7 +2039,8 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     if (e != hipSuccess) return e;
     wavefront_release(ws);
     // + every trace wave's two partly used chunks; a multiple of the chunk size so that both streams stay aligned
-    const uint32_t cap_work = ((quota * n_lp + args.n_units * kWorkChunk + kWorkChunk - 1u) / kWorkChunk) * kWorkChunk;
+    const uint32_t trace_waves = args.cooperative ? args.n_units * kCoopSplit : args.n_units;
+    const uint32_t cap_work = ((quota * n_lp + trace_waves * kWorkChunk + kWorkChunk - 1u) / kWorkChunk) * kWorkChunk;
     // every filter wave owns a region of the queue that holds all shadow rays of its records:
     // at most 2^30 rays (12.9 GB), less when all records of a round cast fewer
     uint64_t qwant = (uint64_t)cap_work * (args.max_shadow_rays ? args.max_shadow_rays : 1u) + 64ull * kMaxFilterWaves;
@@ -2143,10 +2165,8 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         w.jump_n[1] = ws.jump_n[1];
         if (coop && ws.coop_n != want[0]) {
             std::vector<uint32_t> tabs((size_t)kCoopTables * kJumpWords, 0u);
-            for (uint32_t t = 0; t < kCoopTables; ++t) {
-                const uint32_t points = t < 7u ? t + 1u : 8u * (t - 6u);
-                build_jump_table(points * want[0], tabs.data() + (size_t)t * kJumpWords);
-            }
+            for (uint32_t t = 0; t < kCoopTables; ++t) // 4 and 16 shaded points
+                build_jump_table((4u << (2u * t)) * want[0], tabs.data() + (size_t)t * kJumpWords);
             e = hipMemcpyAsync(ws.coop_tabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
             if (e != hipSuccess) return e;
@@ -2177,7 +2197,8 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         // slot tags default to TAG_ADD (0): the trace kernel stores only the rare end-of-call / end-of-pixel marks
         e = hipMemsetAsync(ws.tags, 0, (size_t)ws.quota * ws.n_lp, stream);
         if (e != hipSuccess) return e;
-        const dim3 tgrid((args.n_units + kTraceWaves - 1u) / kTraceWaves), tblock(64 * kTraceWaves);
+        const uint32_t twaves = coop ? args.n_units * kCoopSplit : args.n_units;
+        const dim3 tgrid((twaves + kTraceWaves - 1u) / kTraceWaves), tblock(64 * kTraceWaves);
         if (coop) WF_TIMED(WF_K_TRACE, hipLaunchKernelGGL(wf_trace_kernel<true>, tgrid, tblock, 0, stream, w, first));
         else WF_TIMED(WF_K_TRACE, hipLaunchKernelGGL(wf_trace_kernel<false>, tgrid, tblock, 0, stream, w, first));
         e = hipMemcpyAsync(ws.ctrs_host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);

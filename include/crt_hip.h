@@ -223,12 +223,12 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out);
 int crt_set_pipeline(crt_ctx* ctx, int pipeline);
 /* How the wavefront pipeline's trace kernel walks the last level of the global-illumination tree
  * (the ind_rays children of main.cu:176-191 that expand no further).  Same bits either way.
- *   CRT_TRACE_PER_PIXEL    one lane per pixel pops the children one after the other (default)
- *   CRT_TRACE_COOPERATIVE  the 64 lanes of a wave take one child ray each, one pixel after the other.
- *                          Experimental: a pixel's dependent chain gets 10x shorter, but with 64 pixels
- *                          per wave the batches of one wave still run back to back, and it measures 2x
- *                          slower than per-pixel at every launch size tried
- *   CRT_TRACE_AUTO         per-pixel
+ *   CRT_TRACE_PER_PIXEL    one lane per pixel pops the children one after the other: fewest
+ *                          instructions, best when the launch has enough pixels to fill the GPU
+ *   CRT_TRACE_COOPERATIVE  a wave owns 8 pixels and its 64 lanes take one child ray each: 3.4 times the
+ *                          instructions, but a pixel's dependent chain gets 10x shorter, which wins when
+ *                          every wave would otherwise sit alone on its SIMD (the shards of a multi-GPU job)
+ *   CRT_TRACE_AUTO         cooperative below 100 000 pixels per launch, else per-pixel (default)
  * No counterpart in the reference. */
 #define CRT_TRACE_AUTO 0
 #define CRT_TRACE_PER_PIXEL 1

@@ -20,14 +20,17 @@ def oracle():
     return oracle_lib
 
 
-@pytest.fixture(scope="session", params=["auto", "persistent"])
+@pytest.fixture(scope="session", params=["auto", "per_pixel", "persistent"])
 def gpu_ctx(request):
     """One context per pipeline on cuda:0 shared by the GPU tests (fails loudly without the HIP library
-    or a GPU).  "auto" runs the wavefront kernels wherever they apply (aa_iter <= 1)."""
+    or a GPU).  "auto" is the default configuration: the wavefront kernels, with the cooperative trace
+    kernel for launches below 100 000 pixels; "per_pixel" forces the one-lane-per-pixel trace kernel."""
     import cudaraytracer_amd as crt
     from cudaraytracer_amd import abi
     ctx = crt.Context(0)
-    ctx.set_pipeline(abi.CRT_PIPELINE_AUTO if request.param == "auto" else abi.CRT_PIPELINE_PERSISTENT)
+    ctx.set_pipeline(abi.CRT_PIPELINE_PERSISTENT if request.param == "persistent" else abi.CRT_PIPELINE_AUTO)
+    if request.param == "per_pixel":
+        ctx.set_trace_mode(abi.CRT_TRACE_PER_PIXEL)
     ctx.pipeline_name = request.param
     yield ctx
     ctx.close()

@@ -262,11 +262,12 @@ def test_full_size_gl1_properties(gpu_ctx, oracle):
 
 # ------------------------------------------------------------------ wavefront pipeline specifics
 def _wavefront_ctx(trace_mode=None):
+    """A private wavefront context; per-pixel trace kernel unless told otherwise (the default would pick
+    the cooperative one for these small images, which has its own tests below)."""
     from cudaraytracer_amd import abi
     ctx = crt.Context(0)
     ctx.set_pipeline(abi.CRT_PIPELINE_WAVEFRONT)
-    if trace_mode is not None:
-        ctx.set_trace_mode(trace_mode)
+    ctx.set_trace_mode(abi.CRT_TRACE_PER_PIXEL if trace_mode is None else trace_mode)
     return ctx
 
 

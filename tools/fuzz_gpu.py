@@ -23,8 +23,7 @@ for seed in range(first, first + count):
     ctx = crt.Context(0)
     ctx.set_pipeline(abi.CRT_PIPELINE_PERSISTENT if seed % 8 == 5 else abi.CRT_PIPELINE_WAVEFRONT)
     ctx.set_audit(True)
-    if seed % 8 == 2:
-        ctx.set_trace_mode(abi.CRT_TRACE_COOPERATIVE)
+    ctx.set_trace_mode(abi.CRT_TRACE_COOPERATIVE if seed % 2 == 0 else abi.CRT_TRACE_PER_PIXEL)
     if seed % 7 == 3:
         ctx.set_workspace_limit(1 << 20)
     ctx.upload(scene)
