@@ -100,13 +100,13 @@ crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
 }
 
 // Whether the trace kernel of this launch expands the last GI level cooperatively.  Measured at 720x720
-// gl_iter 1: 64 800 pixels (an eighth of the frame) 4.7 ms against 6.6 ms per-pixel, 129 600 pixels 8.8
-// against 7.3.
+// gl_iter 1, trace + filter kernels: 64 800 pixels (an eighth of the frame) 4.3 ms against 7.5 ms
+// per-pixel, 129 600 pixels 8.6 against 8.8, 259 200 pixels far behind.
 uint32_t pick_cooperative(const crt_ctx* ctx, const crt::RenderArgs& a) {
     if (a.gl_iter == 0) return 0u;
     if (ctx->trace_mode == CRT_TRACE_COOPERATIVE) return 1u;
     if (ctx->trace_mode == CRT_TRACE_PER_PIXEL) return 0u;
-    return (uint64_t)a.n_units * 64u < 100000ull ? 1u : 0u;
+    return (uint64_t)a.n_units * 64u < 150000ull ? 1u : 0u;
 }
 
 // Runs one launch through the pipeline the context selects.

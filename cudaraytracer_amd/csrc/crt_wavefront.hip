@@ -82,7 +82,7 @@ struct WfArgs {
     uint32_t region_cap;  // queue entries per filter wave
     const uint32_t* unit_order; // trace: launch slot -> work unit, most expensive first; null = identity
     float* draws;              // cooperative trace: [2 * CRT_RAY_STACK][n_lp] child draws of the innermost leaf node
-    const uint32_t* coop_tabs; // cooperative trace: kCoopTables more rng_jump tables (4 and 16 shaded points' worth of draws)
+    const uint32_t* coop_tabs; // cooperative trace: kCoopTables rng_jump tables in device memory, table k-1 jumps k shaded points' worth of draws
 };
 
 DI float u2f(uint32_t x) { return __uint_as_float(x); }
@@ -761,11 +761,15 @@ DI uint32_t record_light_class(ScenePtr sc, uint32_t li, const LightF& lf, V3 P)
 
 // ---------------------------------------------------------------------------------------- trace
 constexpr uint32_t kTraceWaves = 4; // waves per trace workgroup (they share the generator jump tables in LDS)
-// Cooperative expansion handles at most 63 children at a time, so that a 64th lane can compute the
-// generator state the pixel continues with; the k-th diffuse hit of a batch starts k shaded points'
-// worth of draws further on, k = 16c + 4b + a: a jumps of one point, b of four, c of sixteen, with the
-// three tables in LDS (at most nine jumps; tables in device memory made every lookup a cache miss).
-constexpr uint32_t kCoopBatch = 63, kCoopTables = 2;
+// Cooperative expansion handles at most 63 children at a time.  The k-th diffuse hit of a batch starts k
+// shaded points' worth of draws after the batch's first; its record keeps the batch's generator state
+// and k (bits 8..13 of the primitive word), and whoever draws from it (the filter kernel, for the fifth
+// of the records whose samples it has to look at) jumps there with table k-1 of 63 in device memory.
+// The owner continues from the state after all of the batch's hits: one jump by one lane.
+constexpr uint32_t kCoopBatch = 63, kCoopTables = 63;
+DI void ordinal_jump(Rng& rng, uint32_t k, const WfArgs& w) { // k shaded points ahead; k = 0 for records of the per-pixel walk
+    if (k != 0u && w.jump_n[0] != 0u) rng_jump(rng, w.coop_tabs + (size_t)(k - 1u) * kJumpWords, k * w.jump_n[0] * 362437u);
+}
 // In the cooperative kernel a wave owns 8 of its unit's 64 pixels (one row of the tile) and kCoopSplit
 // waves share the unit: the batches of one wave run back to back, so fewer owners per wave means more
 // of them in flight.
@@ -855,7 +859,8 @@ DI uint32_t pop_ray(ScenePtr sc, const PrimTable& prim, V3& cur_o, V3& cur_d, V4
 }
 
 // Stores one shade record.
-DI void store_record(const WfArgs& w, uint32_t wi, V3 P, V3 N, V3 view, V4 att, uint32_t geom, const Rng& rng, uint32_t slot) {
+DI void store_record(const WfArgs& w, uint32_t wi, V3 P, V3 N, V3 view, V4 att, uint32_t geom, const Rng& rng, uint32_t slot,
+                     uint32_t ordinal = 0u) {
     if (wi < w.cap_work) {
         uint32_t* r = w.work + wi;
         const size_t cw = w.cap_work;
@@ -872,7 +877,7 @@ DI void store_record(const WfArgs& w, uint32_t wi, V3 P, V3 N, V3 view, V4 att, 
         r[(WK_ATT + 1) * cw] = f2u(att.y);
         r[(WK_ATT + 2) * cw] = f2u(att.z);
         r[(WK_ATT + 3) * cw] = f2u(att.w);
-        r[WK_GEOM * cw] = geom;
+        r[WK_GEOM * cw] = geom | (ordinal << 8);
         r[(WK_RNG + 0) * cw] = rng.v0;
         r[(WK_RNG + 1) * cw] = rng.v1;
         r[(WK_RNG + 2) * cw] = rng.v2;
@@ -1015,16 +1020,10 @@ template <bool COOP>
 __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kernel(WfArgs w, uint32_t first) {
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
-    // [0] one shaded point's draws; per-pixel kernel: [1] the 2 ind_rays child draws; cooperative kernel:
-    // [1], [2] four and sixteen shaded points' draws (it steps or, for inner levels, jumps through a
-    // table in device memory over the child draws)
-    __shared__ __attribute__((aligned(16))) uint32_t s_jump[COOP ? 3 : 2][kJumpWords];
+    __shared__ __attribute__((aligned(16))) uint32_t s_jump[2][kJumpWords];
     __shared__ PrimTable s_prim;
-    for (uint32_t k = threadIdx.x; k < (COOP ? 1u : 2u) * kJumpWords; k += 64u * kTraceWaves)
+    for (uint32_t k = threadIdx.x; k < 2u * kJumpWords; k += 64u * kTraceWaves)
         s_jump[k / kJumpWords][k % kJumpWords] = w.jump_tabs[k];
-    if (COOP)
-        for (uint32_t k = threadIdx.x; k < kCoopTables * kJumpWords; k += 64u * kTraceWaves)
-            s_jump[1u + k / kJumpWords][k % kJumpWords] = w.coop_tabs[k];
     fill_prim_table(sc, s_prim, threadIdx.x, 64u * kTraceWaves);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -1293,7 +1292,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                         // leaf children: keep their draws where any lane of the wave can pick them up
                         for (uint32_t k = 0; k < 2u * accepted; ++k) w.draws[(size_t)k * n_lp + lp] = rng_uniform(rng);
                     } else if (accepted != 0u && 2u * accepted == w.jump_n[1]) {
-                        rng_jump(rng, COOP ? w.jump_tabs + kJumpWords : s_jump[1], 2u * accepted * 362437u);
+                        rng_jump(rng, s_jump[1], 2u * accepted * 362437u);
                     } else {
                         for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
                     }
@@ -1389,18 +1388,10 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                 const uint64_t m_slot = __ballot(outcome != 0u), m_rec = __ballot(outcome == 2u);
                 const uint32_t n_rec = (uint32_t)__popcll(m_rec);
                 const uint32_t slot_k = o_cnt + lane_rank(m_slot);
-                // generator state of the k-th diffuse hit: k shaded points' worth of draws after the owner's;
-                // lane n computes the state the owner continues with (k = n_rec)
-                const uint32_t my_k = outcome == 2u ? lane_rank(m_rec) : (lane == n ? n_rec : 0u);
+                // the k-th diffuse hit's record keeps the owner's generator state and k; lane n computes the
+                // state the owner continues with, n_rec shaded points further on
                 Rng c_rng = o_rng;
-                {
-                    for (uint32_t level = 0; level < 3u && skip_draws != 0u; ++level) { // no light draws: no tables, nothing to skip
-                        const uint32_t digit = (my_k >> (2u * level)) & 3u;
-                        for (uint32_t r = 0; __any(digit > r); ++r)
-                            if (digit > r) rng_jump(c_rng, s_jump[COOP ? level : 0u], 0u);
-                    }
-                    c_rng.d += my_k * skip_draws * 362437u;
-                }
+                if (lane == n) ordinal_jump(c_rng, n_rec, w);
                 PROF_MARK(6);
                 if (outcome == 1u) {
                     const V4 c = r_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
@@ -1409,7 +1400,8 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                 if (m_rec != 0) {
                     const uint32_t my_wi = reserve_records(w, wc, m_rec, lane);
                     if (outcome == 2u)
-                        store_record(w, my_wi, c_P, c_N, c_view, r_att, c_geom, c_rng, (uint32_t)((size_t)slot_k * n_lp + o_lp));
+                        store_record(w, my_wi, c_P, c_N, c_view, r_att, c_geom, o_rng, (uint32_t)((size_t)slot_k * n_lp + o_lp),
+                                     lane_rank(m_rec));
                 }
                 // ---- hand the results back to the owner
                 Rng nr;
@@ -1497,6 +1489,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
 constexpr uint32_t kRecQueueCap = 128; // < 64 left over + 64 new entries per group
 
 // Runs the sample loop of light `li` for up to 64 queued records (one per lane).
+template <bool ORDINALS>
 DI void filter_batch(const WfArgs& w, ScenePtr sc, uint32_t li, const LightF& lf, uint32_t S, uint32_t (*rq)[kRecQueueCap],
                      uint32_t& rqn, uint32_t (*stg)[kStageCap], Stage& st, uint32_t lane, uint32_t& tally) {
     const uint32_t n = rqn < 64u ? rqn : 64u;
@@ -1513,8 +1506,10 @@ DI void filter_batch(const WfArgs& w, ScenePtr sc, uint32_t li, const LightF& lf
     rng.v3 = rq[7][slot];
     rng.v4 = rq[8][slot];
     rng.d = rq[9][slot];
+    const uint32_t ordinal = ORDINALS ? rq[10][slot] : 0u;
     rqn = base;
     __syncthreads();
+    if (ORDINALS && __any(ordinal != 0u)) ordinal_jump(rng, ordinal, w); // a record of a cooperative batch (powers of one map: order is free)
     const RecordFilter rf = make_record_filter(sc, li, lf, P);
     uint32_t shadowed = 0;
     const uint32_t key = wi | (li << 28);
@@ -1532,11 +1527,13 @@ DI void filter_batch(const WfArgs& w, ScenePtr sc, uint32_t li, const LightF& lf
 // For every light: each group of 64 records is first classified as a whole (record_light_class, all
 // lanes busy); records whose samples have to be looked at are compacted through an LDS queue, and the
 // sample loop runs on full batches of 64 of them.
+// ORDINALS: the records may come from the cooperative trace kernel (see kCoopBatch).
+template <bool ORDINALS>
 __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end) {
     ScenePtr sc = (ScenePtr)w.r.scene;
     const uint32_t lane = threadIdx.x;
     __shared__ uint32_t stg[3][kStageCap];
-    __shared__ uint32_t rq[10][kRecQueueCap]; // record index, P, generator state at the light's first draw
+    __shared__ uint32_t rq[11][kRecQueueCap]; // record index, P, generator state (draws_before steps after the record's), the record's ordinal
     Stage st = {0u, 0u, 0u};
     uint32_t rqn = 0; // wave-uniform fill of rq
     uint32_t tally = 0;
@@ -1551,7 +1548,8 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
         for (uint32_t base = blockIdx.x * 64u; base < w_end - w_begin; base += gridDim.x * 64u) {
             const uint32_t wi = w_begin + base + lane;
             const uint32_t wr = wi < w_end ? wi : w_begin;
-            const bool act = wi < w_end && w.work[(size_t)WK_GEOM * cw + wr] != kNoRecord;
+            const uint32_t gword = w.work[(size_t)WK_GEOM * cw + wr];
+            const bool act = wi < w_end && gword != kNoRecord;
             const uint32_t* r = w.work + wr;
             const V3 P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
             const uint32_t c = record_light_class(sc, li, lf, P);
@@ -1579,12 +1577,13 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
                     rq[7][slot] = rng.v3;
                     rq[8][slot] = rng.v4;
                     rq[9][slot] = rng.d;
+                    if (ORDINALS) rq[10][slot] = (gword >> 8) & 63u;
                 }
                 rqn += (uint32_t)__popcll(qm);
-                if (rqn >= 64u) filter_batch(w, sc, li, lf, S, rq, rqn, stg, st, lane, tally);
+                if (rqn >= 64u) filter_batch<ORDINALS>(w, sc, li, lf, S, rq, rqn, stg, st, lane, tally);
             }
         }
-        while (rqn != 0u) filter_batch(w, sc, li, lf, S, rq, rqn, stg, st, lane, tally);
+        while (rqn != 0u) filter_batch<ORDINALS>(w, sc, li, lf, S, rq, rqn, stg, st, lane, tally);
         draws_before += 2u * S;
     }
     if (st.fill != 0u) stage_flush(w, stg, st, st.fill, lane);
@@ -1605,7 +1604,8 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
     for (uint32_t base = blockIdx.x * 64u; base < w_end - w_begin; base += gridDim.x * 64u) {
         const uint32_t wi = w_begin + base + lane;
         const uint32_t wr = wi < w_end ? wi : w_begin;
-        const bool act = wi < w_end && w.work[(size_t)WK_GEOM * cw + wr] != kNoRecord;
+        const uint32_t gword = w.work[(size_t)WK_GEOM * cw + wr];
+        const bool act = wi < w_end && gword != kNoRecord;
         const uint32_t* r = w.work + wr;
         const V3 P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
         Rng rng;
@@ -1615,6 +1615,7 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
         rng.v3 = r[(WK_RNG + 3) * cw];
         rng.v4 = r[(WK_RNG + 4) * cw];
         rng.d = r[(WK_RNG + 5) * cw];
+        if (act) ordinal_jump(rng, (gword >> 8) & 63u, w);
         for (uint32_t li = 0; li < n_lights; ++li) {
             const DevLight CRT_CONST* L = &sc->lights[li];
             if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue;
@@ -1802,8 +1803,9 @@ __global__ void __launch_bounds__(64, 4) wf_shade_kernel(WfArgs w, uint32_t w_be
     const V3 view = mk3(u2f(r[(WK_V + 0) * cw]), u2f(r[(WK_V + 1) * cw]), u2f(r[(WK_V + 2) * cw]));
     const V4 att = V4{u2f(r[(WK_ATT + 0) * cw]), u2f(r[(WK_ATT + 1) * cw]), u2f(r[(WK_ATT + 2) * cw]),
                       u2f(r[(WK_ATT + 3) * cw])};
-    const uint32_t geom = r[WK_GEOM * cw];
-    if (geom == kNoRecord) return;
+    const uint32_t gword = r[WK_GEOM * cw];
+    if (gword == kNoRecord) return;
+    const uint32_t geom = gword & 0xffu; // bits 8..13: the record's ordinal in a cooperative batch
     const uint32_t slot = r[WK_SLOT * cw];
     const DevGeomShade CRT_CONST* gs = &sc->shade[geom];
     V4 direct = V4{0, 0, 0, 0}; // LightList::calculateColor (LightList.hpp:23-36)
@@ -2165,8 +2167,26 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         w.jump_n[1] = ws.jump_n[1];
         if (coop && ws.coop_n != want[0]) {
             std::vector<uint32_t> tabs((size_t)kCoopTables * kJumpWords, 0u);
-            for (uint32_t t = 0; t < kCoopTables; ++t) // 4 and 16 shaded points
-                build_jump_table((4u << (2u * t)) * want[0], tabs.data() + (size_t)t * kJumpWords);
+            // table k-1 = k times the jump of one shaded point: every entry of the previous table, itself a
+            // generator state, is put through the one-point table once more
+            build_jump_table(want[0], tabs.data());
+            for (uint32_t t = 1; t < kCoopTables; ++t) {
+                const uint32_t* prev = tabs.data() + (size_t)(t - 1u) * kJumpWords;
+                uint32_t* next = tabs.data() + (size_t)t * kJumpWords;
+                for (uint32_t en = 0; en < kJumpEntries; ++en) {
+                    const uint32_t in[5] = {prev[4u * en], prev[4u * en + 1u], prev[4u * en + 2u], prev[4u * en + 3u],
+                                            prev[4u * kJumpEntries + en]};
+                    uint32_t out[5] = {0, 0, 0, 0, 0};
+                    for (uint32_t wd = 0; wd < 5u; ++wd)
+                        for (uint32_t nb = 0; nb < 8u; ++nb) {
+                            const uint32_t idx = (wd * 8u + nb) * 16u + ((in[wd] >> (4u * nb)) & 15u);
+                            for (uint32_t o = 0; o < 4u; ++o) out[o] ^= tabs[4u * idx + o];
+                            out[4] ^= tabs[4u * kJumpEntries + idx];
+                        }
+                    for (uint32_t o = 0; o < 4u; ++o) next[4u * en + o] = out[o];
+                    next[4u * kJumpEntries + en] = out[4];
+                }
+            }
             e = hipMemcpyAsync(ws.coop_tabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
             if (e != hipSuccess) return e;
@@ -2223,7 +2243,8 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
                 const uint32_t b1 = n_work - b0 > step ? b0 + step : n_work;
                 const uint32_t groups = (b1 - b0 + 63u) / 64u;
                 const uint32_t fgrid = groups < fwaves ? groups : fwaves;
-                WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1));
+                if (coop) WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel<true>, dim3(fgrid), dim3(64), 0, stream, w, b0, b1));
+                else WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel<false>, dim3(fgrid), dim3(64), 0, stream, w, b0, b1));
                 if (args.audit && attempt == 1u) hipLaunchKernelGGL(wf_audit_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
                 WF_TIMED(WF_K_RESOLVE,
                          hipLaunchKernelGGL(wf_resolve_kernel, dim3(fgrid * kResolveSplit), dim3(64), 0, stream, w));

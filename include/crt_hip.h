@@ -225,10 +225,10 @@ int crt_set_pipeline(crt_ctx* ctx, int pipeline);
  * (the ind_rays children of main.cu:176-191 that expand no further).  Same bits either way.
  *   CRT_TRACE_PER_PIXEL    one lane per pixel pops the children one after the other: fewest
  *                          instructions, best when the launch has enough pixels to fill the GPU
- *   CRT_TRACE_COOPERATIVE  a wave owns 8 pixels and its 64 lanes take one child ray each: 3.4 times the
+ *   CRT_TRACE_COOPERATIVE  a wave owns 8 pixels and its 64 lanes take one child ray each: twice the
  *                          instructions, but a pixel's dependent chain gets 10x shorter, which wins when
  *                          every wave would otherwise sit alone on its SIMD (the shards of a multi-GPU job)
- *   CRT_TRACE_AUTO         cooperative below 100 000 pixels per launch, else per-pixel (default)
+ *   CRT_TRACE_AUTO         cooperative below 150 000 pixels per launch, else per-pixel (default)
  * No counterpart in the reference. */
 #define CRT_TRACE_AUTO 0
 #define CRT_TRACE_PER_PIXEL 1
