@@ -2,6 +2,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -99,14 +100,18 @@ crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
     return a;
 }
 
-// Whether the trace kernel of this launch expands the last GI level cooperatively.  Measured at 720x720
-// gl_iter 1, trace + filter kernels: 64 800 pixels (an eighth of the frame) 4.3 ms against 7.5 ms
-// per-pixel, 129 600 pixels 8.6 against 8.8, 259 200 pixels far behind.
+// Share (per mille) of this launch's work units, most expensive first, that go through the cooperative
+// trace kernel.  Measured at 720x720 gl_iter 1 (trace kernel, ms): 64 800 pixels, an eighth of the frame:
+// all cooperative 3.3, none 6.6; 129 600 pixels: 8 % 4.2, none 7.1, all 6.6; 259 200 pixels: 3 % 5.4, none
+// 8.0; the full frame: none 9.5, 1 % 9.9.  The environment variable is for such measurements
+// (tools/mix_sweep.sh).
 uint32_t pick_cooperative(const crt_ctx* ctx, const crt::RenderArgs& a) {
     if (a.gl_iter == 0) return 0u;
-    if (ctx->trace_mode == CRT_TRACE_COOPERATIVE) return 1u;
+    if (ctx->trace_mode == CRT_TRACE_COOPERATIVE) return 1000u;
     if (ctx->trace_mode == CRT_TRACE_PER_PIXEL) return 0u;
-    return (uint64_t)a.n_units * 64u < 150000ull ? 1u : 0u;
+    if (const char* env = getenv("CRT_COOP_PERMILLE")) return (uint32_t)atoi(env) > 1000u ? 1000u : (uint32_t)atoi(env);
+    const uint64_t pixels = (uint64_t)a.n_units * 64u;
+    return pixels < 100000ull ? 1000u : pixels < 200000ull ? 80u : pixels < 400000ull ? 30u : 0u;
 }
 
 // Runs one launch through the pipeline the context selects.

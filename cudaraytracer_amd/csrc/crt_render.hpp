@@ -30,7 +30,8 @@ struct RenderArgs {
     uint32_t tx, ty, blocks_x, blocks_y, win_bx, win_by, start_bx, start_by; // MODE_PARTIAL
     uint32_t audit;           // wavefront pipeline: also run the filter audit kernel
     uint32_t max_shadow_rays; // shadow rays one diffuse hit casts: sum of shadowSamples over initialised area lights
-    uint32_t cooperative;     // wavefront pipeline: the trace kernel expands the last GI level with one lane per child ray
+    uint32_t cooperative;     // wavefront pipeline: per mille of the work units (most expensive first) whose last GI
+                              // level the trace kernel expands with one lane per child ray; 0 = none, 1000 = all
 };
 
 // ---- wavefront pipeline (crt_wavefront.hip)
@@ -66,6 +67,9 @@ struct WfWorkspace {
     float* draws = nullptr;         // [2 * CRT_RAY_STACK][n_lp]: the (r1, r2) pairs of the innermost node's children
     uint32_t* coop_tabs = nullptr;  // 14 jump tables: 1..7 and 8, 16, .., 56 shaded points' worth of draws
     uint32_t coop_n = 0xffffffffu;  // draws per shaded point the tables were built for
+    void* side_stream = nullptr;    // hipStream_t: the cooperative kernel of a mixed launch runs here
+    void* fork_event = nullptr;     // hipEvent_t pair ordering the side stream against the caller's
+    void* join_event = nullptr;
     size_t bytes = 0;
     // optional per-kernel timing with HIP events on the launch stream (crt_set_timing)
     bool timing = false;

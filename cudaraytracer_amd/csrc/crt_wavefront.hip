@@ -1017,7 +1017,8 @@ __global__ void __launch_bounds__(64) wf_cost_kernel(WfArgs w, uint32_t* unit_co
 }
 
 template <bool COOP>
-__global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kernel(WfArgs w, uint32_t first) {
+__global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kernel(WfArgs w, uint32_t first, uint32_t slot_begin,
+                                                                                   uint32_t slot_end) {
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
     __shared__ __attribute__((aligned(16))) uint32_t s_jump[2][kJumpWords];
@@ -1028,8 +1029,8 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_slot = blockIdx.x * kTraceWaves + (threadIdx.x >> 6);
-    const uint32_t launch_slot = COOP ? wave_slot / kCoopSplit : wave_slot;
-    if (launch_slot >= a.n_units) return;
+    const uint32_t launch_slot = slot_begin + (COOP ? wave_slot / kCoopSplit : wave_slot); // this launch walks [slot_begin, slot_end)
+    if (launch_slot >= slot_end) return;
     const uint32_t unit = w.unit_order ? w.unit_order[launch_slot] : launch_slot; // most expensive units first
     const bool own = !COOP || (lane >> 3) == wave_slot % kCoopSplit; // the pixels this wave walks
     const size_t n_lp = w.n_lp;
@@ -1999,6 +2000,9 @@ void wavefront_release(WfWorkspace& ws) {
     (void)hipFree(ws.qcounts);
     (void)hipFree(ws.draws);
     (void)hipFree(ws.coop_tabs);
+    if (ws.side_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(ws.side_stream));
+    if (ws.fork_event) (void)hipEventDestroy(static_cast<hipEvent_t>(ws.fork_event));
+    if (ws.join_event) (void)hipEventDestroy(static_cast<hipEvent_t>(ws.join_event));
     (void)hipFree(ws.unit_cost);
     (void)hipFree(ws.unit_order);
     (void)hipHostFree(ws.unit_host);
@@ -2136,6 +2140,22 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     w.unit_order = nullptr;
     const bool coop = args.cooperative != 0u && args.gl_iter != 0u;
     if (coop && (!ws.draws || !ws.coop_tabs)) return hipErrorInvalidValue; // wavefront_reserve was given other arguments
+    uint32_t n_coop = 0; // units for the cooperative kernel: that share of the launch, at least one unit
+    if (coop) {
+        n_coop = (uint32_t)(((uint64_t)args.n_units * (args.cooperative > 1000u ? 1000u : args.cooperative) + 999u) / 1000u);
+        if (n_coop > args.n_units) n_coop = args.n_units;
+        if (n_coop != args.n_units && !ws.side_stream) {
+            hipStream_t s2 = nullptr;
+            hipEvent_t ev1 = nullptr, ev2 = nullptr;
+            e = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev1, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev2, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+            ws.side_stream = s2;
+            ws.fork_event = ev1;
+            ws.join_event = ev2;
+        }
+    }
 
     // shadow rays per shade record, for sizing the filter batches
     // Filter launches: G persistent waves, each takes every G-th group of 64 records and owns a queue
@@ -2217,10 +2237,33 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         // slot tags default to TAG_ADD (0): the trace kernel stores only the rare end-of-call / end-of-pixel marks
         e = hipMemsetAsync(ws.tags, 0, (size_t)ws.quota * ws.n_lp, stream);
         if (e != hipSuccess) return e;
-        const uint32_t twaves = coop ? args.n_units * kCoopSplit : args.n_units;
-        const dim3 tgrid((twaves + kTraceWaves - 1u) / kTraceWaves), tblock(64 * kTraceWaves);
-        if (coop) WF_TIMED(WF_K_TRACE, hipLaunchKernelGGL(wf_trace_kernel<true>, tgrid, tblock, 0, stream, w, first));
-        else WF_TIMED(WF_K_TRACE, hipLaunchKernelGGL(wf_trace_kernel<false>, tgrid, tblock, 0, stream, w, first));
+        {
+            // The first n_coop units of the launch order (the most expensive ones) go through the cooperative
+            // kernel, the rest through the per-pixel one; when both run, the cooperative kernel goes to a side
+            // stream so that the two share the GPU.
+            EventTimer::Span* span = timer ? timer->begin(WF_K_TRACE, stream) : nullptr;
+            const dim3 tblock(64 * kTraceWaves);
+            const uint32_t rest = args.n_units - n_coop;
+            hipStream_t cstream = stream;
+            if (n_coop != 0u && rest != 0u) {
+                cstream = static_cast<hipStream_t>(ws.side_stream);
+                e = hipEventRecord(static_cast<hipEvent_t>(ws.fork_event), stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(cstream, static_cast<hipEvent_t>(ws.fork_event), 0);
+                if (e != hipSuccess) return e;
+            }
+            if (n_coop != 0u)
+                hipLaunchKernelGGL(wf_trace_kernel<true>, dim3((n_coop * kCoopSplit + kTraceWaves - 1u) / kTraceWaves), tblock, 0,
+                                   cstream, w, first, 0u, n_coop);
+            if (rest != 0u)
+                hipLaunchKernelGGL(wf_trace_kernel<false>, dim3((rest + kTraceWaves - 1u) / kTraceWaves), tblock, 0, stream, w, first,
+                                   n_coop, args.n_units);
+            if (cstream != stream) {
+                e = hipEventRecord(static_cast<hipEvent_t>(ws.join_event), cstream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(stream, static_cast<hipEvent_t>(ws.join_event), 0);
+                if (e != hipSuccess) return e;
+            }
+            EventTimer::end(span, stream);
+        }
         e = hipMemcpyAsync(ws.ctrs_host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(stream);

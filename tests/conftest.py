@@ -24,7 +24,7 @@ def oracle():
 def gpu_ctx(request):
     """One context per pipeline on cuda:0 shared by the GPU tests (fails loudly without the HIP library
     or a GPU).  "auto" is the default configuration: the wavefront kernels, with the cooperative trace
-    kernel for launches below 150 000 pixels; "per_pixel" forces the one-lane-per-pixel trace kernel."""
+    kernel for launches below 100 000 pixels; "per_pixel" forces the one-lane-per-pixel trace kernel."""
     import cudaraytracer_amd as crt
     from cudaraytracer_amd import abi
     ctx = crt.Context(0)

@@ -491,3 +491,24 @@ def test_glass_walk_inside_spheres_with_untrusted_quads(oracle, gpu_ctx, seed, a
     ref, _, ref_state = oracle.render(random_scene(oracle, seed, S, wild=True), st, seed, want_state=True)
     assert np.array_equal(state, ref_state)
     assert np.array_equal(fb, ref), f"{np.count_nonzero(fb != ref)} floats differ, max {np.abs(fb - ref).max()}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,aa,gl,ind,S,share", [(40, 1, 1, 75, 8, 350), (24, 2, 2, 7, 3, 500), (33, 1, 1, 9, 5, 1)])
+def test_mixed_trace_launch_matches_oracle(oracle, monkeypatch, n, aa, gl, ind, S, share):
+    """A launch in which the most expensive units go through the cooperative trace kernel on a second stream
+    and the rest through the per-pixel kernel (what the default does between 100 000 and 400 000 pixels);
+    CRT_COOP_PERMILLE forces that split on a small image."""
+    from cudaraytracer_amd import abi
+    monkeypatch.setenv("CRT_COOP_PERMILLE", str(share))
+    ctx = _wavefront_ctx(abi.CRT_TRACE_AUTO)
+    try:
+        st = crt.make_settings(nx=n, ny=n - 4, aa_iter=aa, gl_iter=gl, ind_rays=ind, shadowSamples=S)
+        fb, state = _gpu_render(ctx, crt.cornell_box(S), st, 77)
+        fb2, state2 = _gpu_render(ctx, crt.cornell_box(S), st, 77)  # the side stream and its events are reused
+        ref, _, ref_state = oracle.render(oracle.cornell(S), st, 77, want_state=True)
+        assert np.array_equal(state, ref_state), "sample trees diverged"
+        assert np.array_equal(fb, ref), f"{np.count_nonzero(fb != ref)} floats differ"
+        assert np.array_equal(fb2, fb) and np.array_equal(state2, state)
+    finally:
+        ctx.close()
