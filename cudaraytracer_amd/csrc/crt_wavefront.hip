@@ -1857,11 +1857,31 @@ __global__ void __launch_bounds__(64) wf_sum_kernel(WfArgs w, uint32_t first) {
     }
     const uint32_t aa_iter = a.aa_iter > 4u ? 4u : a.aa_iter; // main.cu:233
     uint32_t verdict = AA_PENDING;
+    // Slots are fetched four at a time, tag and contribution alike (a slot that is not an addition has an
+    // unused, but allocated, contribution), and consumed in order: one round trip to memory per four slots
+    // instead of two per slot.
+    constexpr uint32_t kAhead = 4;
+    uint32_t tags[kAhead];
+    float4 contribs[kAhead];
     for (uint32_t k = 0; k < cnt; ++k) {
-        const uint32_t tag = w.tags[(size_t)k * n_lp + lp];
+        if (k % kAhead == 0u) {
+#pragma unroll
+            for (uint32_t j = 0; j < kAhead; ++j) {
+                const uint32_t kk = k + j < cnt ? k + j : cnt - 1u;
+                tags[j] = w.tags[(size_t)kk * n_lp + lp];
+                contribs[j] = w.contrib[(size_t)kk * n_lp + lp];
+            }
+        }
+        uint32_t tag = tags[0];
+        float4 c = contribs[0];
+#pragma unroll
+        for (uint32_t j = 1; j < kAhead; ++j)
+            if (k % kAhead == j) {
+                tag = tags[j];
+                c = contribs[j];
+            }
         const uint32_t type = tag & 3u;
         if (type == TAG_ADD) {
-            const float4 c = w.contrib[(size_t)k * n_lp + lp];
             final_c = final_c + V4{c.x, c.y, c.z, c.w};
         } else if (type == TAG_END_CALL) {
             // aa_color's use of a finished color() call (main.cu:254-300)
