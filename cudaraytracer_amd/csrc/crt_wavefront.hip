@@ -765,8 +765,41 @@ constexpr uint32_t kTraceWaves = 4; // waves per trace workgroup (they share the
 // shaded points' worth of draws after the batch's first; its record keeps the batch's generator state
 // and k (bits 8..13 of the primitive word), and whoever draws from it (the filter kernel, for the fifth
 // of the records whose samples it has to look at) jumps there with table k-1 of 63 in device memory.
-// The owner continues from the state after all of the batch's hits: one jump by one lane.
+// The owner continues from the state after all of the batch's hits (ordinal_jump_wave); 63 children
+// keep every ordinal and the hit count within the 63 tables.
 constexpr uint32_t kCoopBatch = 63, kCoopTables = 63;
+// The same jump for a state and a k that are uniform over the wave, done by the wave: lane e < 40 looks up
+// nibble e of the state, an XOR butterfly adds the forty images up, and every lane ends with the result.
+// One trip to the table instead of forty dependent on one lane's address arithmetic.
+DI void ordinal_jump_wave(Rng& rng, uint32_t k, const WfArgs& w, uint32_t lane) {
+    if (k == 0u || w.jump_n[0] == 0u) return;
+    const uint32_t* tab = w.coop_tabs + (size_t)(k - 1u) * kJumpWords;
+    const uint32_t wd = lane >> 3, nb = lane & 7u;
+    const uint32_t word = wd == 0u ? rng.v0 : wd == 1u ? rng.v1 : wd == 2u ? rng.v2 : wd == 3u ? rng.v3 : rng.v4;
+    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+    if (lane < 40u) {
+        const uint32_t idx = lane * 16u + ((word >> (4u * nb)) & 15u);
+        const uint4 q = reinterpret_cast<const uint4*>(tab)[idx];
+        o0 = q.x;
+        o1 = q.y;
+        o2 = q.z;
+        o3 = q.w;
+        o4 = tab[4u * kJumpEntries + idx];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        o0 ^= __shfl_xor(o0, off, 64);
+        o1 ^= __shfl_xor(o1, off, 64);
+        o2 ^= __shfl_xor(o2, off, 64);
+        o3 ^= __shfl_xor(o3, off, 64);
+        o4 ^= __shfl_xor(o4, off, 64);
+    }
+    rng.v0 = o0;
+    rng.v1 = o1;
+    rng.v2 = o2;
+    rng.v3 = o3;
+    rng.v4 = o4;
+    rng.d += k * w.jump_n[0] * 362437u;
+}
 DI void ordinal_jump(Rng& rng, uint32_t k, const WfArgs& w) { // k shaded points ahead; k = 0 for records of the per-pixel walk
     if (k != 0u && w.jump_n[0] != 0u) rng_jump(rng, w.coop_tabs + (size_t)(k - 1u) * kJumpWords, k * w.jump_n[0] * 362437u);
 }
@@ -1389,10 +1422,10 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                 const uint64_t m_slot = __ballot(outcome != 0u), m_rec = __ballot(outcome == 2u);
                 const uint32_t n_rec = (uint32_t)__popcll(m_rec);
                 const uint32_t slot_k = o_cnt + lane_rank(m_slot);
-                // the k-th diffuse hit's record keeps the owner's generator state and k; lane n computes the
-                // state the owner continues with, n_rec shaded points further on
-                Rng c_rng = o_rng;
-                if (lane == n) ordinal_jump(c_rng, n_rec, w);
+                // the k-th diffuse hit's record keeps the owner's generator state and k; the owner continues
+                // n_rec shaded points further on
+                Rng nr = o_rng;
+                ordinal_jump_wave(nr, n_rec, w, lane);
                 PROF_MARK(6);
                 if (outcome == 1u) {
                     const V4 c = r_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
@@ -1405,13 +1438,6 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                                      lane_rank(m_rec));
                 }
                 // ---- hand the results back to the owner
-                Rng nr;
-                nr.v0 = (uint32_t)__builtin_amdgcn_readlane((int)c_rng.v0, (int)n);
-                nr.v1 = (uint32_t)__builtin_amdgcn_readlane((int)c_rng.v1, (int)n);
-                nr.v2 = (uint32_t)__builtin_amdgcn_readlane((int)c_rng.v2, (int)n);
-                nr.v3 = (uint32_t)__builtin_amdgcn_readlane((int)c_rng.v3, (int)n);
-                nr.v4 = (uint32_t)__builtin_amdgcn_readlane((int)c_rng.v4, (int)n);
-                nr.d = (uint32_t)__builtin_amdgcn_readlane((int)c_rng.d, (int)n);
                 // the direction register keeps the last ray that had a usable direction (main.cu:138)
                 const V3 last_d = mk3(u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.x), (int)(n - 1u))),
                                       u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.y), (int)(n - 1u))),
