@@ -457,19 +457,22 @@ def test_cooperative_trace_random_scenes(oracle, seed):
 
 
 @pytest.mark.gpu
-def test_trace_modes_agree_on_a_shard():
-    """The per-pixel and the cooperative trace give the same compact shard buffer (720x720, rank 3 of 8)."""
+@pytest.mark.parametrize("rank,world", [(3, 8), (1, 4), (0, 2)])
+def test_trace_modes_agree_on_a_shard(rank, world):
+    """720x720 shards at the sizes where the default picks the cooperative trace kernel for all units (1/8),
+    or for the most expensive ones next to the per-pixel kernel (1/4, 1/2): same compact buffer and RNG end
+    states as with the per-pixel kernel alone."""
     from cudaraytracer_amd import abi
     st = crt.make_settings(gl_iter=1, ind_rays=20, shadowSamples=8)
-    n = crt.shard_tiles_max(st.nx, st.ny, 8) * 64 * 4
+    n = crt.shard_tiles_max(st.nx, st.ny, world) * 64 * 4
     out = []
-    for mode in (abi.CRT_TRACE_PER_PIXEL, abi.CRT_TRACE_COOPERATIVE):
+    for mode in (abi.CRT_TRACE_PER_PIXEL, abi.CRT_TRACE_AUTO):
         ctx = _wavefront_ctx(mode)
         try:
             ctx.upload(crt.cornell_box(8))
             ctx.rng_init(st.nx, st.ny, 5)
             buf = ctx.fb_alloc(n)
-            ctx.render_shard(st, 3, 8, buf)
+            ctx.render_shard(st, rank, world, buf)
             out.append((ctx.fb_download(buf, n), ctx.rng_export(st.nx, st.ny)))
             ctx.fb_free(buf)
         finally:
