@@ -4,14 +4,18 @@
 // The reference walks each pixel's sample tree depth-first inside one thread.  Its control flow
 // (which rays exist, which generator draws they use) does not depend on any shading result as long
 // as aa_iter <= 1, and colours are only ever *added*, in tree order.  The work is therefore split
-// into five dense kernels that hand records to each other through HBM:
+// into dense kernels that hand records to each other through HBM:
 //
 //   trace    one lane per pixel walks the tree (camera rays, mirror/glass bounces, GI children) with
 //            the pixel's XORWOW stream, but shades nothing: every diffuse hit becomes a shade record
 //            {P, N, view, attenuation, primitive, generator state, result slot} and the generator is
 //            stepped past the 2*shadowSamples draws the hit will consume.  Misses write their
 //            (attenuation x black) term straight into their result slot.  A pixel fills at most
-//            `quota` slots per round and keeps its traversal state in HBM between rounds.
+//            `quota` slots per round and keeps its traversal state in HBM between rounds.  In small
+//            launches (and for the most expensive pixels of medium ones) a second form of the kernel
+//            expands the last GI level with one lane per child ray instead (see kCoopBatch).
+//   cost     ordering only: estimates every 64-pixel unit's number of tree steps, so that the trace
+//            kernel can start the expensive units first.
 //   filter   one lane per shade record draws the light samples and classifies every shadow ray with
 //            division-free tests against the primitives that survive a per-record cull: certainly
 //            free, certainly blocked by an opaque primitive, or undecided.  Undecided rays (a few per
