@@ -1,4 +1,4 @@
-"""Long form of the random-scene parity test: python tools/fuzz_gpu.py FIRST COUNT [wild] (needs a GPU)."""
+"""Long form of the random-scene parity test: python tools/fuzz_gpu.py FIRST COUNT [wild|wide] (needs a GPU)."""
 import sys
 from pathlib import Path
 
@@ -12,13 +12,21 @@ import oracle_lib  # noqa: E402
 from scene_fuzz import random_scene  # noqa: E402
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
-wild = len(sys.argv) > 3 and sys.argv[3] == "wild"
+wild = len(sys.argv) > 3 and sys.argv[3] in ("wild", "wide")
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
 failures = 0
 for seed in range(first, first + count):
     S = 3 + seed % 7
     gl = 2 if seed % 11 == 10 else 1
-    st = crt.make_settings(nx=36, ny=28, aa_iter=(1, 1, 1, 1, 2, 1, 3, 1, 0, 4)[seed % 10], gl_iter=gl, ind_rays=5 if gl == 1 else 3,
-                           shadowSamples=S)
+    if wide:  # settings vary too: children beyond one batch and beyond the ray stack, few or many bounces, odd image sizes
+        prng = np.random.default_rng(seed + 13_000_000)
+        gl = int(prng.choice([1, 1, 1, 2, 3]))
+        ind = int(prng.choice([2, 5, 9, 70, 130])) if gl == 1 else int(prng.choice([2, 3, 9 if gl == 2 else 4]))
+        st = crt.make_settings(nx=int(prng.integers(5, 40)), ny=int(prng.integers(5, 30)), aa_iter=int(prng.choice([0, 1, 1, 2, 3])),
+                               ref_iter=int(prng.choice([1, 2, 4, 6])), gl_iter=gl, ind_rays=ind, shadowSamples=S)
+    else:
+        st = crt.make_settings(nx=36, ny=28, aa_iter=(1, 1, 1, 1, 2, 1, 3, 1, 0, 4)[seed % 10], gl_iter=gl,
+                               ind_rays=5 if gl == 1 else 3, shadowSamples=S)
     scene = random_scene(crt, seed, S, wild)
     ctx = crt.Context(0)
     ctx.set_pipeline(abi.CRT_PIPELINE_PERSISTENT if seed % 8 == 5 else abi.CRT_PIPELINE_WAVEFRONT)
