@@ -1,6 +1,7 @@
 """Seeded random scenes for parity tests: spheres of every material that may overlap each other and the
-walls, tilted parallelograms and in-plane skewed quadrilaterals, one or two area lights of arbitrary
-orientation (parallelogram or not, one- or two-sided), sometimes a point light, sometimes a missing wall.
+walls, tilted parallelograms, trapezoids, general and non-planar quadrilaterals (small ones too), one or two
+area lights of arbitrary orientation (parallelogram or not, one- or two-sided), sometimes a point light,
+sometimes a missing wall.
 
 The same POD records build the product's scene (mod = cudaraytracer_amd) and the checker's (mod = the
 oracle wrapper), so both sides see identical floats."""
