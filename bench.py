@@ -21,8 +21,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-# README.md:131-133 of the reference (RTX 4070 Ti SUPER), seconds per render
-README_4070TIS_S = {"gl0": 0.116, "gl1": 10.438, "gl2": 574.214}
+# README.md:131-134 of the reference (RTX 4070 Ti SUPER), seconds per render
+README_4070TIS_S = {"gl0": 0.116, "gl1": 10.438, "gl2": 574.214, "gl3": 23040.602}
 PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak (needs packed v_pk_fma_f32; see peak_note)
 
 
@@ -66,7 +66,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["gl0", "gl1", "gl2"], default="gl1")
+    ap.add_argument("--workload", choices=["gl0", "gl1", "gl2", "gl3"], default="gl1",
+                    help="README benchmark row; gl3 takes about 80 s per step on one GPU")
     ap.add_argument("--nx", type=int, default=720)
     ap.add_argument("--ny", type=int, default=720)
     ap.add_argument("--seed", type=int, default=1234)
