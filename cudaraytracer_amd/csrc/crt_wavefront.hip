@@ -1869,6 +1869,9 @@ __global__ void __launch_bounds__(64, 4) wf_shade_kernel(WfArgs w, uint32_t w_be
 }
 
 // ------------------------------------------------------------------------------------------ sum
+// AHEAD: slots fetched four at a time (small launches, where the chain of dependent loads is what the
+// kernel waits for; a large launch has enough waves to hide it and only pays for the extra selects).
+template <bool AHEAD>
 __global__ void __launch_bounds__(64) wf_sum_kernel(WfArgs w, uint32_t first) {
     const RenderArgs& a = w.r;
     const uint32_t lane = threadIdx.x, unit = blockIdx.x;
@@ -1887,10 +1890,10 @@ __global__ void __launch_bounds__(64) wf_sum_kernel(WfArgs w, uint32_t first) {
     }
     const uint32_t aa_iter = a.aa_iter > 4u ? 4u : a.aa_iter; // main.cu:233
     uint32_t verdict = AA_PENDING;
-    // Slots are fetched four at a time, tag and contribution alike (a slot that is not an addition has an
-    // unused, but allocated, contribution), and consumed in order: one round trip to memory per four slots
-    // instead of two per slot.
-    constexpr uint32_t kAhead = 4;
+    // AHEAD: tag and contribution alike are fetched four slots at a time (a slot that is not an addition
+    // has an unused, but allocated, contribution) and consumed in order: one round trip to memory per four
+    // slots instead of two per slot.
+    constexpr uint32_t kAhead = AHEAD ? 4 : 1;
     uint32_t tags[kAhead];
     float4 contribs[kAhead];
     for (uint32_t k = 0; k < cnt; ++k) {
@@ -2358,7 +2361,8 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         }
         if (n_work != 0u)
             WF_TIMED(WF_K_SHADE, hipLaunchKernelGGL(wf_shade_kernel, dim3((n_work + 63u) / 64u), dim3(64), 0, stream, w, 0u, n_work));
-        WF_TIMED(WF_K_SUM, hipLaunchKernelGGL(wf_sum_kernel, dim3(args.n_units), dim3(64), 0, stream, w, first));
+        if (args.n_units < 4096u) WF_TIMED(WF_K_SUM, hipLaunchKernelGGL(wf_sum_kernel<true>, dim3(args.n_units), dim3(64), 0, stream, w, first));
+        else WF_TIMED(WF_K_SUM, hipLaunchKernelGGL(wf_sum_kernel<false>, dim3(args.n_units), dim3(64), 0, stream, w, first));
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         first = 0u;
