@@ -237,12 +237,24 @@ def test_readme_row0_full_size_is_bit_exact_and_matches_the_reference_render(gpu
 
 
 def test_full_size_gl1_properties(gpu_ctx, oracle):
-    """BASELINE configs[2] (720x720, gl_iter=1): too slow for the CPU checker in full, so: determinism, a
-    checked crop, the exact work count, and agreement of the image mean with a second seed."""
+    """BASELINE configs[2] (720x720, gl_iter=1): the CPU checker needs minutes for the full frame, so every
+    pixel and final generator state is compared with its frozen render (checksums, whole and per 16 rows:
+    tests/golden/make_oracle_frames.py), a crop is re-rendered by the checker here, and determinism, the
+    exact work count and agreement of the image mean with a second seed are checked on top."""
+    import json
+    from pathlib import Path
+    from frame_digest import digest
     st = crt.make_settings(gl_iter=1)
     scene = crt.cornell_box(50)
     a, sa = _gpu_render(gpu_ctx, scene, st, 1234)
     stats = gpu_ctx.stats(st)
+    frozen = json.loads((Path(__file__).resolve().parent / "golden" / "oracle_full_frames.json").read_text())["cornell_720_gl1"]
+    mine = digest(a, sa)
+    bad = [i for i, (x, y) in enumerate(zip(mine["image_bands"], frozen["image_bands"])) if x != y]
+    assert not bad, f"rows {[16 * i for i in bad[:8]]}... differ from the CPU restatement's frame"
+    assert mine["image_sha256"] == frozen["image_sha256"] and mine["state_sha256"] == frozen["state_sha256"]
+    assert stats.rng_draws == frozen["rng_draws"] and stats.shade_points == frozen["shade_points"]
+    assert stats.gi_children == frozen["gi_children"]
     b, sb = _gpu_render(gpu_ctx, scene, st, 1234)
     assert np.array_equal(a, b) and np.array_equal(sa, sb)
     c, _ = _gpu_render(gpu_ctx, scene, st, 4321)
