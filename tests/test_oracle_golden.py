@@ -122,3 +122,21 @@ def test_reference_render_statistics_are_self_consistent():
     b = np.array(STATS["file75.hdr"]["mean_rgb"])
     assert np.allclose(a, b, rtol=1e-4)
     assert STATS["file.hdr"]["mean_rgb"] == STATS["renders/render2.hdr"]["mean_rgb"]
+
+
+def test_frozen_full_frame_is_what_the_oracle_renders(oracle):
+    """The 720x720 gl_iter=1 frame frozen as checksums (golden/oracle_full_frames.json, the GPU test's
+    full-size comparison) is reproduced by the oracle on one band of 16 rows, image and end states."""
+    import hashlib
+    import json
+    from frame_digest import BAND
+    frozen = json.loads((GOLD / "oracle_full_frames.json").read_text())["cornell_720_gl1"]
+    st = abi.make_settings(gl_iter=1)
+    band = 31                                   # rows 496..511: through both spheres
+    y0 = band * BAND
+    fb, _, state = oracle.render(oracle.cornell(50), st, 1234, region=(0, y0, 720, y0 + BAND), want_state=True)
+    rows = np.ascontiguousarray(fb[y0:y0 + BAND], dtype=np.float32)
+    assert hashlib.sha256(rows.tobytes()).hexdigest()[:16] == frozen["image_bands"][band]
+    srows = np.ascontiguousarray(state).reshape(720, 720, -1)[y0:y0 + BAND]
+    assert hashlib.sha256(srows.tobytes()).hexdigest()[:16] == frozen["state_bands"][band]
+    assert len(frozen["image_bands"]) == 45 and frozen["band_rows"] == BAND
