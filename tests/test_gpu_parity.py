@@ -493,6 +493,39 @@ def test_trace_modes_agree_on_a_shard(rank, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_full_size_shards_match_the_frozen_frame(world):
+    """The benchmark workload rendered as `world` shards with the default trace mode (what each rank of a
+    multi-GPU run launches: mixed kernels for a half and a quarter of the frame, the cooperative kernel for
+    an eighth), scattered into one frame: all pixels and end states equal the CPU restatement's frozen frame."""
+    import json
+    from pathlib import Path
+    import torch
+    from cudaraytracer_amd import abi, distributed as shard
+    from frame_digest import digest
+    frozen = json.loads((Path(__file__).resolve().parent / "golden" / "oracle_full_frames.json").read_text())["cornell_720_gl1"]
+    st = crt.make_settings(gl_iter=1)
+    nx, ny = st.nx, st.ny
+    ctx = _wavefront_ctx(abi.CRT_TRACE_AUTO)
+    try:
+        ctx.upload(crt.cornell_box(50))
+        ctx.rng_init(nx, ny, 1234)
+        kmax = shard.shard_tiles_max(nx, ny, world)
+        gathered = torch.zeros((world, kmax * 256), device="cuda:0")
+        for r in range(world):
+            ctx.render_shard(st, r, world, gathered[r].data_ptr())
+        fb = torch.empty((ny, nx, 4), device="cuda:0")
+        ctx.scatter_shards(nx, ny, world, gathered.data_ptr(), fb.data_ptr())
+        torch.cuda.synchronize()
+        mine = digest(fb.cpu().numpy(), ctx.rng_export(nx, ny))
+    finally:
+        ctx.close()
+    bad = [i for i, (x, y) in enumerate(zip(mine["image_bands"], frozen["image_bands"])) if x != y]
+    assert not bad, f"rows {[16 * i for i in bad[:8]]}... differ from the CPU restatement's frame"
+    assert mine["image_sha256"] == frozen["image_sha256"] and mine["state_sha256"] == frozen["state_sha256"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed,aa", [(300918, 0), (301969, 4)])
 def test_glass_walk_inside_spheres_with_untrusted_quads(oracle, gpu_ctx, seed, aa):
     """Scaled scenes full of glass, found by tools/fuzz_gpu.py: a shadow ray inside a glass sphere meets a glass
