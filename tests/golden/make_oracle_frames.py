@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Freezes the CPU restatement's full-size gl_iter=1 render (720x720, seed 1234, the benchmark workload)
-as checksums, so that the GPU test can compare all 518400 pixels and final generator states bit for bit
-without paying the CPU render (about two minutes on 8 cores) in every run.
+"""Freezes whole frames of the CPU restatement (CASES below; first of all the benchmark workload, 720x720
+gl_iter=1) as checksums, so that the GPU tests can compare every pixel and final generator state bit for
+bit without paying minutes of CPU render in every run.
 
-    python tests/golden/make_oracle_frames.py        # writes tests/golden/oracle_full_frames.json
+    python tests/golden/make_oracle_frames.py [case ...]   # updates tests/golden/oracle_full_frames.json
 
 Data only: SHA-256 of the float32 RGBA image and of the uint32 generator states, whole and per band of 16
 rows (a mismatch then names the band), plus the work counters.
@@ -24,20 +24,29 @@ import cudaraytracer_amd as crt  # noqa: E402
 from frame_digest import BAND, digest  # noqa: E402
 
 
+CASES = {  # name: (image side, aa_iter, gl_iter); ref_iter 4, ind_rays 75, 50 shadow samples, seed 1234
+    "cornell_720_gl1": (720, 1, 1),     # the benchmark workload, three minutes on 8 cores
+    "cornell_128_gl2": (128, 1, 2),     # two GI levels: ~22 000 shaded points per pixel, many pipeline rounds
+    "cornell_256_aa3_gl1": (256, 3, 1), # adaptive anti-aliasing three levels deep on top of one GI level
+}
+
+
 def main():
-    out = {}
-    for gl in (1,):
-        st = crt.make_settings(gl_iter=gl)
+    path = HERE / "oracle_full_frames.json"
+    out = json.loads(path.read_text()) if path.exists() else {}
+    for name in (sys.argv[1:] or list(CASES)):
+        n, aa, gl = CASES[name]
+        st = crt.make_settings(nx=n, ny=n, aa_iter=aa, gl_iter=gl)
         t0 = time.perf_counter()
         fb, cnt, state = O.render(O.cornell(50), st, 1234, want_state=True)
         d = digest(fb, state)
-        d.update({"nx": int(st.nx), "ny": int(st.ny), "seed": 1234, "band_rows": BAND,
+        d.update({"nx": n, "ny": n, "aa_iter": aa, "gl_iter": gl, "seed": 1234, "band_rows": BAND,
                   "rng_draws": int(cnt.rng_draws), "shade_points": int(cnt.shade_points),
                   "gi_children": int(cnt.gi_children),
                   "mean_rgba": [float(x) for x in fb.reshape(-1, 4).astype(np.float64).mean(0)]})
-        out[f"cornell_720_gl{gl}"] = d
-        print(f"gl_iter={gl}: {time.perf_counter() - t0:.1f} s", d["image_sha256"], flush=True)
-    (HERE / "oracle_full_frames.json").write_text(json.dumps(out, indent=1))
+        out[name] = d
+        print(f"{name}: {time.perf_counter() - t0:.1f} s", d["image_sha256"], flush=True)
+        path.write_text(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":

@@ -272,6 +272,26 @@ def test_full_size_gl1_properties(gpu_ctx, oracle):
     assert np.array_equal(sa[idx], ref_state[idx])
 
 
+@pytest.mark.parametrize("case", ["cornell_128_gl2", "cornell_256_aa3_gl1"])
+def test_frozen_frames(gpu_ctx, case):
+    """Whole frames the CPU restatement needs minutes for (two GI levels; adaptive anti-aliasing three levels
+    deep over one GI level), frozen as checksums by tests/golden/make_oracle_frames.py: every pixel, every end
+    state and the work counters."""
+    import json
+    from pathlib import Path
+    from frame_digest import digest
+    frozen = json.loads((Path(__file__).resolve().parent / "golden" / "oracle_full_frames.json").read_text())[case]
+    st = crt.make_settings(nx=frozen["nx"], ny=frozen["ny"], aa_iter=frozen["aa_iter"], gl_iter=frozen["gl_iter"])
+    fb, state = _gpu_render(gpu_ctx, crt.cornell_box(50), st, frozen["seed"])
+    stats = gpu_ctx.stats(st)
+    mine = digest(fb, state)
+    bad = [i for i, (x, y) in enumerate(zip(mine["image_bands"], frozen["image_bands"])) if x != y]
+    assert not bad, f"rows {[16 * i for i in bad[:8]]}... differ from the CPU restatement's frame"
+    assert mine["image_sha256"] == frozen["image_sha256"] and mine["state_sha256"] == frozen["state_sha256"]
+    assert stats.rng_draws == frozen["rng_draws"] and stats.shade_points == frozen["shade_points"]
+    assert stats.gi_children == frozen["gi_children"]
+
+
 # ------------------------------------------------------------------ wavefront pipeline specifics
 def _wavefront_ctx(trace_mode=None):
     """A private wavefront context; per-pixel trace kernel unless told otherwise (the default would pick
