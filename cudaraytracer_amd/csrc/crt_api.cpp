@@ -182,6 +182,7 @@ int crt_scene_upload(crt_ctx* ctx, const crt_scene_desc* scene) {
     if ((rc = bind(ctx)) != CRT_OK) return rc;
     HIP_TRY(ctx, hipDeviceSynchronize()); // no render may still be reading the old scene
     HIP_TRY(ctx, hipMemcpy(ctx->scene_dev, &ctx->scene_host, sizeof(crt::DevScene), hipMemcpyHostToDevice));
+    ctx->wf.order_valid = false; // the trace kernel's launch order was estimated on the old scene
     ctx->has_scene = true;
     return CRT_OK;
 }

@@ -445,6 +445,20 @@ struct Hit {
     float t, u, v;
 };
 
+// reflectance<true>(cosine, ri) > 1.0f (math_functions.hpp:106-133; main.cu:97, Light.hpp:61).  (1 - cosine)^5
+// is evaluated as ((x*x)*(x*x))*x.  With cosine in [0,1] the test cannot hold, but it is not dead: at a
+// grazing hit the direction, normalised once more (main.cu:91), can change the sign of d.n, cosine comes
+// out as -6e-8 and the ray is mirrored instead of refracted.
+// Early out: for cosine >= 0 and ri >= 0 every factor lies in [0,1] and r0 + fl(1 - r0) rounds to at most 1
+// (1 - r0 is exact for r0 >= 1/2 and off by at most 2^-25 otherwise), so the comparison is false.
+DI bool reflectance_over_one(float cosine, float ri) {
+    if (cosine >= 0.0f && ri >= 0.0f) return false;
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    const float x = 1.0f - cosine, x2 = x * x;
+    return r0 + (1.0f - r0) * ((x2 * x2) * x) > 1.0f;
+}
+
 // GeometryList::hit (GeometryList.hpp:22-35): closest hit, ties and unordered
 // distances go to the later primitive.  The loop index is wave-uniform, so each
 // primitive costs one 8-dword scalar load.
@@ -558,8 +572,7 @@ DI bool covered_through_glass(ScenePtr sc, const DevLight CRT_CONST* L, V3 o, V3
         V3 rd = normalize3(d);
         float cos_theta = __builtin_fminf(dot3(neg(rd), norm), 1.0f);
         float sin_theta = rcp_exact(rsqrt_c(1.0f - cos_theta * cos_theta));
-        // reflectance(...) > 1.0f (Light.hpp:61) cannot hold for cos_theta in [0,1]; only the TIR test remains.
-        if (ratio * sin_theta > 1.0f) return true;
+        if (ratio * sin_theta > 1.0f || reflectance_over_one(cos_theta, ratio)) return true; // Light.hpp:61
         V3 dir = refract3(rd, norm, ratio);
         V3 ro = P + dir * 0.01f;
         V3 rdir = ray_dir(dir);

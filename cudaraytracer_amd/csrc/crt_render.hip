@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(64, CRT_WAVES_PER_EU) render_kernel(RenderArgs
                                 V3 rdn = normalize3(ray_d);
                                 float cos_theta = __builtin_fminf(dot3(neg(rdn), norm), 1.0f);
                                 float sin_theta = rcp_exact(rsqrt_c(1.0f - cos_theta * cos_theta));
-                                bool cannot_refract = ratio * sin_theta > 1.0f; // reflectance(...) > 1 never holds
+                                bool cannot_refract = ratio * sin_theta > 1.0f || reflectance_over_one(cos_theta, ratio); // main.cu:97
                                 V3 dir = cannot_refract ? reflect3(rdn, norm) : refract3(rdn, norm, ratio);
                                 cur_o = P + dir * 0.01f;
                                 cur_d = dir;

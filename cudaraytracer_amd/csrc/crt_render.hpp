@@ -63,6 +63,8 @@ struct WfWorkspace {
     uint32_t* unit_cost = nullptr;  // [n_units] cost estimate per work unit (float bits)
     uint32_t* unit_order = nullptr; // [n_units] launch order of the trace kernel
     uint32_t* unit_host = nullptr;  // pinned: [n_units] costs, then [n_units] order
+    bool order_valid = false;       // unit_order holds the order for order_key (same scene upload)
+    RenderArgs order_key{};         // launch whose order unit_order holds: the estimate depends on scene, camera and pixel mapping only
     // cooperative trace only
     float* draws = nullptr;         // [2 * CRT_RAY_STACK][n_lp]: the (r1, r2) pairs of the innermost node's children
     uint32_t* coop_tabs = nullptr;  // 14 jump tables: 1..7 and 8, 16, .., 56 shaded points' worth of draws

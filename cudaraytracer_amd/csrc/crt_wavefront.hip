@@ -885,7 +885,7 @@ DI uint32_t pop_ray(ScenePtr sc, const PrimTable& prim, V3& cur_o, V3& cur_d, V4
         V3 rdn = normalize3(ray_d);
         float cos_theta = __builtin_fminf(dot3(neg(rdn), norm), 1.0f);
         float sin_theta = rcp_exact(rsqrt_c(1.0f - cos_theta * cos_theta));
-        bool cannot_refract = ratio * sin_theta > 1.0f; // reflectance(...) > 1 never holds
+        bool cannot_refract = ratio * sin_theta > 1.0f || reflectance_over_one(cos_theta, ratio); // main.cu:97
         V3 dir = cannot_refract ? reflect3(rdn, norm) : refract3(rdn, norm, ratio);
         cur_o = P + dir * 0.01f;
         cur_d = dir;
@@ -1289,7 +1289,17 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                     const V4 att = cur_att;
                     V3 P = mk3(0, 0, 0), N = mk3(0, 0, 0);
                     uint32_t geom = 0;
+#ifdef CRT_SHADE_TRACE
+                    const V3 o_ = cur_o;
+                    const uint32_t ref_ = cur_ref;
+#endif
                     const uint32_t what = pop_ray(sc, s_prim, cur_o, cur_d, cur_att, cur_ref, ray_d, P, N, geom);
+#ifdef CRT_SHADE_TRACE // the rays of that pixel, in the form of the CPU checker's ORC_TRACE lines
+                    if (pm.valid && pm.j * a.nx + pm.i == (uint32_t)(CRT_SHADE_TRACE))
+                        printf("gpu: ray o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) depth %u ref %u: %s at (%.9g %.9g %.9g) primitive %u N=(%.9g %.9g %.9g)\n",
+                               o_.x, o_.y, o_.z, ray_d.x, ray_d.y, ray_d.z, cur_depth, ref_,
+                               what == POP_MISS ? "miss" : (what == POP_DIFFUSE ? "diffuse hit" : "bounce"), P.x, P.y, P.z, geom, N.x, N.y, N.z);
+#endif
                     if (what == POP_MISS) {
                         // final_color += attenuation * Color::black() (main.cu:149-151)
                         const V4 c = att * V4{0.0f, 0.0f, 0.0f, 1.0f};
@@ -2035,6 +2045,16 @@ void build_jump_table(uint32_t nsteps, uint32_t* tab) {
 
 bool wavefront_supports(const RenderArgs&) { return true; }
 
+// Whether two launches map work units to pixels and rays the same way and walk trees of the same shape
+// (everything wf_cost_kernel reads, apart from the scene's contents).
+static bool same_pixel_mapping(const RenderArgs& a, const RenderArgs& b) {
+    return a.scene == b.scene && a.n_units == b.n_units && a.nx == b.nx && a.ny == b.ny && a.ref_iter == b.ref_iter &&
+           a.gl_iter == b.gl_iter && a.ind_rays == b.ind_rays && a.mode == b.mode && a.tiles_x == b.tiles_x &&
+           a.tiles_y == b.tiles_y && a.rank == b.rank && a.world == b.world && a.tx == b.tx && a.ty == b.ty &&
+           a.blocks_x == b.blocks_x && a.blocks_y == b.blocks_y && a.win_bx == b.win_bx && a.win_by == b.win_by &&
+           a.start_bx == b.start_bx && a.start_by == b.start_by;
+}
+
 void wavefront_release(WfWorkspace& ws) {
     (void)hipFree(ws.ctrs);
     (void)hipHostFree(ws.ctrs_host);
@@ -2268,7 +2288,10 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     }
     // Launch order of the trace kernel's units (most expensive first).  Worth a host round trip only when
     // pixels take many steps and the launch is large enough to have late starters.
-    if (args.gl_iter != 0u && args.n_units > 1u) {
+    if (args.gl_iter != 0u && args.n_units > 1u && ws.order_valid && same_pixel_mapping(args, ws.order_key)) {
+        w.unit_order = ws.unit_order; // same scene, camera and mapping as the last launch: same estimate
+    } else if (args.gl_iter != 0u && args.n_units > 1u) {
+        ws.order_valid = false;
         hipLaunchKernelGGL(wf_cost_kernel, dim3(args.n_units), dim3(64), 0, stream, w, ws.unit_cost);
         e = hipMemcpyAsync(ws.unit_host, ws.unit_cost, (size_t)args.n_units * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -2280,6 +2303,8 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         e = hipMemcpyAsync(ws.unit_order, order, (size_t)args.n_units * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
         w.unit_order = ws.unit_order;
+        ws.order_key = args;
+        ws.order_valid = true;
     }
     uint32_t first = 1u;
     e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_COUNT * sizeof(uint32_t), stream);

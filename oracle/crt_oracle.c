@@ -383,11 +383,15 @@ typedef struct {
     uint32_t* rng;
 } ctx_t;
 
-/* math_functions.hpp:106-133; its result is only ever compared with > 1.0f */
+/* math_functions.hpp:106-133; its result is only ever compared with > 1.0f.  __powf(x, 5) is an
+ * approximation that only the CUDA device reproduces; the canonical form here is ((x*x)*(x*x))*x.
+ * For cosine in [0,1] the result cannot exceed 1; it does at grazing hits where the second
+ * normalisation of the direction (main.cu:91) flips the sign of d.n and cosine comes out as -6e-8. */
 static float reflectance_c(float cosine, float ri) {
     float r0 = fdiv(1.0f - ri, 1.0f + ri);
     r0 = r0 * r0;
-    return r0 + (1.0f - r0) * powf(1.0f - cosine, 5.0f);
+    float x = 1.0f - cosine, x2 = x * x;
+    return r0 + (1.0f - r0) * ((x2 * x2) * x);
 }
 
 /* Texture::sample with CLAMP wrap, Texture.hpp:249-252,126-185,211-237 */
@@ -702,6 +706,10 @@ static v4 color(const ctx_t* cx, v3 ro, v3 rd, unsigned ref_iter, unsigned gl_it
             final = v4_add(final, v4_mul(st.att, sky));
             continue;
         }
+        if (orc_trace_enabled())
+            fprintf(stderr, "oracle: ray o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) depth %u ref %u: hit t=%.9g at (%.9g %.9g %.9g) material %u\n",
+                    ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, st.depth, st.ref_left, hit.t, hit.p.x, hit.p.y, hit.p.z,
+                    (unsigned)hit.mat->type);
         v4 mat_diff = v4_from(hit.mat->diffuse);
         float mat_ref_idx = hit.mat->refractIndex;
         switch (hit.mat->type) {

@@ -580,3 +580,19 @@ def test_mixed_trace_launch_matches_oracle(oracle, monkeypatch, n, aa, gl, ind, 
         assert np.array_equal(fb2, fb) and np.array_equal(state2, state)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_grazing_glass_hit_is_mirrored_like_the_reference(oracle, gpu_ctx):
+    """Found by tools/fuzz_gpu.py (seed 3103556, "wide"): a ray meets a glass sphere with d.n = -2e-9; the
+    direction normalised once more (main.cu:91) gives cos_theta = -6e-8, Schlick's reflectance comes out above 1
+    and get_refraction_ray (main.cu:97) mirrors the ray.  The `reflectance > 1` test is false for every
+    cos_theta in [0,1], but it is not dead code."""
+    from scene_fuzz import random_scene
+    seed = 3103556
+    S = 3 + seed % 7
+    st = crt.make_settings(nx=26, ny=26, aa_iter=3, ref_iter=6, gl_iter=1, ind_rays=70, shadowSamples=S)
+    fb, state = _gpu_render(gpu_ctx, random_scene(crt, seed, S, wild=True), st, seed)
+    ref, _, ref_state = oracle.render(random_scene(oracle, seed, S, wild=True), st, seed, want_state=True)
+    assert np.array_equal(state, ref_state)
+    assert np.array_equal(fb, ref), f"pixels {np.argwhere((fb != ref).any(-1))[:4].tolist()} differ"
