@@ -14,6 +14,7 @@
  *     __fdividef(a,b) -> a / b            rsqrtf(x) -> 1.0f / sqrtf(x)
  *     __saturatef(x)  -> fminf(fmaxf(x,0),1)
  *     __tanf/__powf   -> libm tanf/powf (per-camera / per-material constants)
+ *     __powf(x, 5)    -> ((x*x)*(x*x))*x in Schlick's reflectance (per glass hit; only compared with 1)
  *     __sinf/__cosf   -> orc_sincos() below (a fixed polynomial, so that CPU and
  *                        GPU can agree bit for bit; |err| < 2e-7)
  * Vector helpers follow mstd: dot/length_sq accumulate from 0 in index order
