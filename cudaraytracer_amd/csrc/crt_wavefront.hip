@@ -2288,8 +2288,12 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     }
     // Launch order of the trace kernel's units (most expensive first).  Worth a host round trip only when
     // pixels take many steps and the launch is large enough to have late starters.
-    if (args.gl_iter != 0u && args.n_units > 1u && ws.order_valid && same_pixel_mapping(args, ws.order_key)) {
-        w.unit_order = ws.unit_order; // same scene, camera and mapping as the last launch: same estimate
+    // The order is reused while scene, camera and mapping stay the same (same estimate), except by mixed
+    // launches: a half-frame launch with both trace kernels measured 0.6 ms slower when it is queued behind
+    // the previous frame instead of entering an idle GPU after the pre-pass's host round trip.
+    const bool mixed = n_coop != 0u && n_coop != args.n_units;
+    if (args.gl_iter != 0u && args.n_units > 1u && !mixed && ws.order_valid && same_pixel_mapping(args, ws.order_key)) {
+        w.unit_order = ws.unit_order;
     } else if (args.gl_iter != 0u && args.n_units > 1u) {
         ws.order_valid = false;
         hipLaunchKernelGGL(wf_cost_kernel, dim3(args.n_units), dim3(64), 0, stream, w, ws.unit_cost);
@@ -2318,7 +2322,9 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         {
             // The first n_coop units of the launch order (the most expensive ones) go through the cooperative
             // kernel, the rest through the per-pixel one; when both run, the cooperative kernel goes to a side
-            // stream so that the two share the GPU.
+            // stream so that the two share the GPU.  (Measured on the half-frame launch, trace time: this way
+            // round, launched into an idle GPU after the pre-pass's host round trip, 5.2 ms; the kernels' streams
+            // swapped, or the launch queued behind the previous frame without the round trip, 5.9 ms.)
             EventTimer::Span* span = timer ? timer->begin(WF_K_TRACE, stream) : nullptr;
             const dim3 tblock(64 * kTraceWaves);
             const uint32_t rest = args.n_units - n_coop;
