@@ -6,11 +6,17 @@ Run in the build container only (needs /root/reference):
     python tests/golden/make_fixtures.py
 
 Outputs (data only -- decoded pixel statistics and one output image of the reference):
-  reference_hdr_stats.json   per-file mean RGB of the six .hdr renders, their header text and, for
-                             renders/render0.hdr (gl_iter=0), the 16x16-block mean image (45x45x3)
+  reference_hdr_stats.json   per-file mean RGB of the six .hdr renders, their header text, the SHA-256 of
+                             the file and of its decoded RGBE bytes, and the 16x16-block mean image (45x45x3)
+                             of every render whose settings the README records (gl_iter 0, 2, 2, 3); plus
+                             "gl2_seed_band": the largest block-mean difference between the reference's two
+                             gl_iter=2 renders (two seeds) -- the noise band of a block-mean comparison
+                             Every file is re-encoded with the product's writer (crt_encode_hdr, a host
+                             function) and must come back byte for byte, or the script stops.
   render0.hdr                byte copy of renders/render0.hdr, the reference's own output for README
                              row 0; pins the byte format of the .hdr writer
 """
+import hashlib
 import json
 import shutil
 import sys
@@ -20,6 +26,8 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE.parent))
+sys.path.insert(0, str(HERE.parent.parent))
+import cudaraytracer_amd as crt  # noqa: E402  (crt_encode_hdr only: no GPU needed)
 from hdr_codec import decode_hdr, rgbe_to_float  # noqa: E402
 
 REF = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
@@ -31,6 +39,7 @@ FILES = {
     "file75.hdr": "gl_iter=2, ind_rays=75, another seed (settings not recorded)",
     "file5.hdr": "settings not recorded",
 }
+BLOCKS = ("renders/render0.hdr", "renders/render1.hdr", "renders/render2.hdr", "file75.hdr")
 
 
 def main():
@@ -40,18 +49,31 @@ def main():
         header, rgbe = decode_hdr(raw)
         img = rgbe_to_float(rgbe)
         entry = {"note": note, "header": header, "height": int(img.shape[0]), "width": int(img.shape[1]),
-                 "bytes": len(raw), "mean_rgb": [float(x) for x in img.reshape(-1, 3).mean(0)]}
-        if rel == "renders/render0.hdr":
+                 "bytes": len(raw), "mean_rgb": [float(x) for x in img.reshape(-1, 3).astype(np.float64).mean(0)]}
+        entry["file_sha256"] = hashlib.sha256(raw).hexdigest()
+        entry["rgbe_sha256"] = hashlib.sha256(np.ascontiguousarray(rgbe).tobytes()).hexdigest()
+        # the writer under test reproduces the reference's file from its decoded (mid-bucket) colours
+        again = crt.encode_hdr(img)
+        if again != raw:
+            raise SystemExit(f"{rel}: re-encoding differs from the reference's bytes")
+        entry["reencode_identical"] = True
+        if rel in BLOCKS:
             h, w, _ = img.shape
-            blocks = img.reshape(h // 16, 16, w // 16, 16, 3).mean((1, 3))
-            entry["block16_mean"] = np.round(blocks, 6).tolist()
+            blocks = img.reshape(h // 16, 16, w // 16, 16, 3).astype(np.float64).mean((1, 3))
+            entry["block16_mean"] = np.round(blocks, 7).tolist()
         stats[rel] = entry
+    a = np.array(stats["renders/render1.hdr"]["block16_mean"])
+    b = np.array(stats["file75.hdr"]["block16_mean"])
+    stats["gl2_seed_band"] = {"note": "renders/render1.hdr vs file75.hdr, 16x16 block means",
+                              "max_abs": float(np.abs(a - b).max()), "mean_abs": float(np.abs(a - b).mean()),
+                              "max_rel_mean_rgb": float(np.abs(np.array(stats["renders/render1.hdr"]["mean_rgb"]) /
+                                                               np.array(stats["file75.hdr"]["mean_rgb"]) - 1).max())}
     (HERE / "reference_hdr_stats.json").write_text(json.dumps(stats, indent=1))
     shutil.copyfile(REF / "renders/render0.hdr", HERE / "render0.hdr")
     (HERE / "render0.hdr").chmod(0o644)
     print("wrote", HERE / "reference_hdr_stats.json", "and render0.hdr")
     for k, v in stats.items():
-        print(k, v["mean_rgb"])
+        print(k, v.get("mean_rgb", v))
 
 
 if __name__ == "__main__":

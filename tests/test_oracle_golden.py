@@ -110,9 +110,27 @@ def test_full_size_gl0_against_anchors_and_reference_render(oracle):
     diff = np.abs(fb[..., :3] - ref)
     assert diff.mean() < 1.5e-3                      # RGBE quantisation + different seed + fast-math
     assert (diff.max(-1) <= 0.02).mean() > 0.995
-    assert np.allclose(fb[..., :3].reshape(-1, 3).astype(np.float64).mean(0), STATS["renders/render0.hdr"]["mean_rgb"], rtol=2e-3)
-    blocks = fb[..., :3].reshape(45, 16, 45, 16, 3).mean((1, 3))
-    assert np.abs(blocks - np.array(STATS["renders/render0.hdr"]["block16_mean"])).max() < 0.02
+    # like for like: this frame through the reference's writer (stb's truncating RGBE) and the same reader
+    import cudaraytracer_amd as crt
+    _, mine_rgbe = decode_hdr(crt.encode_hdr(fb))
+    mine = rgbe_to_float(mine_rgbe).astype(np.float64)
+    mean = mine.reshape(-1, 3).mean(0)
+    assert np.abs(mean / np.array(STATS["renders/render0.hdr"]["mean_rgb"]) - 1.0).max() < 5e-4   # measured 1.8e-4
+    d = mine - ref.astype(np.float64)
+    blocks = np.abs(d.reshape(45, 16, 45, 16, 3).mean((1, 3))).max(-1)
+    # Where the two images really differ: the samples that lie exactly on the image diagonals see the
+    # edge between two walls (or a wall and the floor/ceiling) -- an exact tie between two planes, decided by
+    # the last bit of two quotients, which an IEEE build and the reference's --use_fast_math build round
+    # differently.  Nearly every pixel that is off by more than 0.05 sits there, and only blocks on the
+    # diagonals show a deterministic offset (the same for every seed).
+    i = np.arange(45)
+    on_diag = np.zeros((45, 45), bool)
+    on_diag[i, i] = on_diag[i, 44 - i] = True
+    assert blocks[~on_diag].max() < 0.003            # measured 0.0020
+    assert blocks[on_diag].max() < 0.006             # measured 0.0046
+    big = np.argwhere(np.abs(d).max(-1) > 0.05)
+    tied = [(r, c) for r, c in big if r == c or r + c == 720]
+    assert len(big) < 400 and len(tied) > 0.9 * len(big)   # measured 193 of 201
 
 
 def test_reference_render_statistics_are_self_consistent():
