@@ -48,6 +48,7 @@ def lib():
             "crt_rng_init": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
             "crt_rng_export": (C.c_int, [C.c_void_p, C.c_void_p]),
             "crt_render": (C.c_int, [C.c_void_p, P(abi.crt_settings), C.c_void_p, C.c_void_p]),
+            "crt_render_static": (C.c_int, [C.c_void_p, P(abi.crt_settings), C.c_void_p, C.c_void_p]),
             "crt_render_partial": (C.c_int, [C.c_void_p, P(abi.crt_settings), C.c_uint32, C.c_void_p, C.c_void_p]),
             "crt_render_shard": (C.c_int, [C.c_void_p, P(abi.crt_settings), C.c_uint32, C.c_uint32, C.c_void_p,
                                            C.c_void_p]),
@@ -83,7 +84,7 @@ def lib():
 
 ABI_SYMBOLS = (
     "crt_create", "crt_destroy", "crt_last_error", "crt_cornell_scene", "crt_scene_upload", "crt_rng_init",
-    "crt_rng_export", "crt_render", "crt_render_partial", "crt_render_shard", "crt_shard_tiles",
+    "crt_rng_export", "crt_render", "crt_render_static", "crt_render_partial", "crt_render_shard", "crt_shard_tiles",
     "crt_shard_tiles_max", "crt_scatter_shards", "crt_stats_since_init", "crt_selftest_rcp", "crt_set_pipeline",
     "crt_set_trace_mode",
     "crt_set_workspace_limit", "crt_reserve_workspace", "crt_set_audit", "crt_audit_result", "crt_set_timing",
@@ -158,6 +159,10 @@ class Context:
     # -- render into caller-owned device memory (an integer device address)
     def render(self, settings, fb_ptr, stream=None):
         self._check(lib().crt_render(self._h, C.byref(settings), fb_ptr, stream), "crt_render")
+
+    def render_static(self, settings, fb_ptr, stream=None):
+        """crt_render without any device allocation (persistent kernel, scratch in a static device array)."""
+        self._check(lib().crt_render_static(self._h, C.byref(settings), fb_ptr, stream), "crt_render_static")
 
     def render_partial(self, settings, tile_index, fb_ptr, stream=None):
         self._check(lib().crt_render_partial(self._h, C.byref(settings), tile_index, fb_ptr, stream),

@@ -1,5 +1,5 @@
 // C ABI of libcrt_hip.so (declarations and contracts: include/crt_hip.h).
-#include <hip/hip_runtime_api.h>
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,8 +16,17 @@
 extern "C" const unsigned char crt_ltc_tables_blob[];
 extern "C" const unsigned char crt_ltc_tables_blob_end[];
 
+// Scratch of crt_render_static, the entry point that allocates nothing: the persistent kernel's work-unit
+// cursor and wave tallies (first 256 bytes) and its two per-pixel work counters.  Every GPU the library runs
+// on holds its own copy of this array until the process ends; crt_create looks up that copy's address once
+// per device.  In host code the array's name is only a handle for that lookup, never an address to use.
+#define CRT_STATIC_HEAD_WORDS 64u
+static __device__ __align__(256) uint32_t scratch[CRT_STATIC_HEAD_WORDS + 2u * CRT_STATIC_MAX_PIXELS];
+static uint32_t* g_scratch_ptr[64] = {nullptr}; // per device: device address of `scratch` there
+
 struct crt_ctx {
     int device = 0;
+    uint32_t* scratch_ptr = nullptr; // g_scratch_ptr[device]
     char err[512] = {0};
     float* ltc_dev = nullptr;
     crt::DevScene* scene_dev = nullptr;
@@ -153,6 +162,21 @@ int crt_create(crt_ctx** out, int device) {
         crt_destroy(ctx);
         return CRT_ERR_HIP;
     }
+    // this device's copy of the static scratch array (the device is current), and the persistent kernel's
+    // grid size: neither is looked up again by crt_render_static
+    if (device < 64 && g_scratch_ptr[device] == nullptr) {
+        uint32_t* ptr = nullptr;
+        if (hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)) != hipSuccess || ptr == nullptr) {
+            crt_destroy(ctx);
+            return CRT_ERR_HIP;
+        }
+        g_scratch_ptr[device] = ptr;
+    }
+    if (crt::prime_render_grid() != hipSuccess) {
+        crt_destroy(ctx);
+        return CRT_ERR_HIP;
+    }
+    ctx->scratch_ptr = device < 64 ? g_scratch_ptr[device] : nullptr; // null: crt_render_static reports it
     *out = ctx;
     return CRT_OK;
 }
@@ -241,6 +265,32 @@ int crt_render(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void* stream
     a.mode = crt::MODE_FULL;
     a.n_units = a.tiles_x * a.tiles_y;
     return run_render(ctx, a, (hipStream_t)stream);
+}
+
+int crt_render_static(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void* stream) {
+    if (!ctx) return CRT_ERR_INVALID;
+    if (!fb_dev) return fail(ctx, CRT_ERR_INVALID, "fb_dev is NULL");
+    int rc = check_settings(ctx, st);
+    if (rc != CRT_OK) return rc;
+    if ((uint64_t)st->nx * st->ny > CRT_STATIC_MAX_PIXELS)
+        return fail(ctx, CRT_ERR_UNSUPPORTED, "crt_render_static: %ux%u pixels exceed CRT_STATIC_MAX_PIXELS (%u)", st->nx,
+                    st->ny, (unsigned)CRT_STATIC_MAX_PIXELS);
+    if (!ctx->scratch_ptr) return fail(ctx, CRT_ERR_HIP, "crt_render_static: no scratch address for device %d", ctx->device);
+    if ((rc = bind(ctx)) != CRT_OK) return rc;
+    crt::RenderArgs a = base_args(ctx, st, fb_dev);
+    a.mode = crt::MODE_FULL;
+    a.n_units = a.tiles_x * a.tiles_y;
+    // the kernel's scratch comes from the static array: cursor at word 0, wave tallies at word 16, then the
+    // per-pixel counters, which start at zero for this call (the cursor is cleared by launch_render)
+    uint32_t* sp = ctx->scratch_ptr;
+    const size_t npix = (size_t)st->nx * st->ny;
+    a.unit_counter = sp;
+    a.wave_tallies = reinterpret_cast<unsigned long long*>(sp + 16);
+    a.counters = sp + CRT_STATIC_HEAD_WORDS;
+    a.audit = 0u;
+    HIP_TRY(ctx, hipMemsetAsync(sp, 0, (CRT_STATIC_HEAD_WORDS + 2u * npix) * sizeof(uint32_t), (hipStream_t)stream));
+    HIP_TRY(ctx, crt::launch_render(a, (hipStream_t)stream));
+    return CRT_OK;
 }
 
 int crt_render_partial(crt_ctx* ctx, const crt_settings* st, uint32_t tileIndex, float* fb_dev, void* stream) {

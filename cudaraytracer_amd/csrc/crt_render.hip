@@ -702,14 +702,14 @@ __global__ void __launch_bounds__(256) selftest_rcp_kernel(unsigned long long* _
 void launch_random_init(uint32_t npix, uint64_t seed, uint32_t* state, hipStream_t stream) {
     hipLaunchKernelGGL(random_init_kernel, dim3((npix + 63u) / 64u), dim3(64), 0, stream, npix, seed, state);
 }
-hipError_t launch_render(const RenderArgs& args, hipStream_t stream) {
-    // Persistent grid: as many one-wave workgroups as the device keeps resident, never more than there are units.
-    static int resident_waves[64] = {0};
+// Persistent grid: as many one-wave workgroups as the device keeps resident, never more than there are units.
+static int g_resident_waves[64] = {0};
+hipError_t prime_render_grid() {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (resident_waves[dev] == 0) {
+    if (g_resident_waves[dev] == 0) {
         int per_cu = 0, cus = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, 64, 0);
         if (e != hipSuccess) return e;
@@ -717,10 +717,18 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream) {
         if (e != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 16) per_cu = 16; // 4 waves per SIMD saturate VALU issue
-        resident_waves[dev] = per_cu * cus;
+        g_resident_waves[dev] = per_cu * cus;
     }
+    return hipSuccess;
+}
+hipError_t launch_render(const RenderArgs& args, hipStream_t stream) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (g_resident_waves[dev] == 0 && (e = prime_render_grid()) != hipSuccess) return e;
     if (args.n_units == 0) return hipSuccess;
-    uint32_t grid = args.n_units < (uint32_t)resident_waves[dev] ? args.n_units : (uint32_t)resident_waves[dev];
+    uint32_t grid = args.n_units < (uint32_t)g_resident_waves[dev] ? args.n_units : (uint32_t)g_resident_waves[dev];
     e = hipMemsetAsync(args.unit_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(render_kernel, dim3(grid), dim3(64), 0, stream, args);

@@ -98,6 +98,9 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
 
 void launch_random_init(uint32_t npix, uint64_t seed, uint32_t* state, hipStream_t stream);
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream);
+// Looks up the persistent kernel's grid size for the current device (cached); launch_render does it on first
+// use otherwise.
+hipError_t prime_render_grid();
 void launch_selftest_rcp(unsigned long long* mismatches, uint32_t* first_bad, hipStream_t stream);
 void launch_scatter(uint32_t nx, uint32_t ny, uint32_t tiles_x, uint32_t tiles_y, uint32_t world, uint32_t tiles_max,
                     const float* gathered, float* fb, hipStream_t stream);

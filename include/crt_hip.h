@@ -179,6 +179,19 @@ int crt_rng_export(crt_ctx* ctx, uint32_t* host_state6);
  * pixel once into fb_dev (nx*ny RGBA float, row-major, index (j*nx+i)*4+c) and
  * advances the per-pixel RNG states. */
 int crt_render(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void* stream);
+/* crt_render for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same image and same RNG end
+ * states as crt_render, always through the persistent kernel (CRT_PIPELINE_PERSISTENT), asynchronous on
+ * `stream`.  The kernel's scratch (work-unit cursor, wave tallies, two work counters per pixel) lives in a
+ * static device array of 64 + 2 * CRT_STATIC_MAX_PIXELS words (8 MiB) that every GPU the library runs on
+ * holds until the process ends; the call makes no hipMalloc/hipFree and no allocating library call (set-up
+ * -- crt_create, crt_scene_upload, crt_rng_init -- has allocated what the context owns).  Images of more than
+ * CRT_STATIC_MAX_PIXELS pixels are refused with CRT_ERR_UNSUPPORTED.  All calls on one GPU share that GPU's
+ * array (the part a call uses is cleared on `stream` first): calls that overlap on one GPU -- two streams,
+ * two contexts or two threads -- race on it, so keep them on one stream or serialise them.  The work
+ * counters of these calls stay in the array and are not part of crt_stats_since_init. */
+#define CRT_STATIC_MAX_PIXELS (1u << 20)
+int crt_render_static(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void* stream);
 /* Replaces one render_partial launch of the progressive loop (main.cu:349-368,
  * 719-759): renders the window of bx*by reference blocks (tx*ty pixels each)
  * that starts at block (tileIndex % blocksX, min(tileIndex / blocksX, blocksY))
