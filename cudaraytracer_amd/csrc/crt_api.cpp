@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -134,7 +135,16 @@ int run_render(crt_ctx* ctx, const crt::RenderArgs& args, hipStream_t stream) {
         HIP_TRY(ctx, crt::launch_render(a, stream));
         return CRT_OK;
     }
-    HIP_TRY(ctx, crt::wavefront_reserve(ctx->wf, a, ctx->scene_host.n_lights, ctx->workspace_limit));
+    const hipError_t reserved = crt::wavefront_reserve(ctx->wf, a, ctx->scene_host.n_lights, ctx->workspace_limit);
+    if (reserved != hipSuccess) {
+        // no workspace (device memory exhausted): the persistent kernel needs none, so the default pipeline
+        // still renders; only an explicit request for the wavefront kernels reports the failure
+        (void)hipGetLastError();
+        if (ctx->pipeline == CRT_PIPELINE_WAVEFRONT)
+            return fail(ctx, CRT_ERR_HIP, "wavefront workspace: %s", hipGetErrorString(reserved));
+        HIP_TRY(ctx, crt::launch_render(a, stream));
+        return CRT_OK;
+    }
     bool overflow = false;
     HIP_TRY(ctx, crt::launch_wavefront(a, ctx->wf, stream, &overflow));
     if (overflow) return fail(ctx, CRT_ERR_HIP, "wavefront pipeline: a device queue overflowed");
@@ -201,12 +211,18 @@ const char* crt_last_error(const crt_ctx* ctx) { return ctx ? ctx->err : "null c
 int crt_scene_upload(crt_ctx* ctx, const crt_scene_desc* scene) {
     if (!ctx) return CRT_ERR_INVALID;
     if (!scene) return fail(ctx, CRT_ERR_INVALID, "scene is NULL");
-    int rc = crt::flatten_scene(scene, &ctx->scene_host, ctx->err, sizeof ctx->err);
+    // Flattened into a scratch copy first: a scene that is rejected half way must leave the context's host
+    // mirror (which sizes the pipeline's queues and jump tables) and the device copy describing the same,
+    // previous scene.
+    auto flat = std::make_unique<crt::DevScene>();
+    int rc = crt::flatten_scene(scene, flat.get(), ctx->err, sizeof ctx->err);
     if (rc != CRT_OK) return rc;
     if ((rc = bind(ctx)) != CRT_OK) return rc;
     HIP_TRY(ctx, hipDeviceSynchronize()); // no render may still be reading the old scene
-    HIP_TRY(ctx, hipMemcpy(ctx->scene_dev, &ctx->scene_host, sizeof(crt::DevScene), hipMemcpyHostToDevice));
-    ctx->wf.order_valid = false; // the trace kernel's launch order was estimated on the old scene
+    ctx->has_scene = false;               // until the device holds the new one
+    ctx->wf.order_valid = false;          // the trace kernel's launch order was estimated on the old scene
+    HIP_TRY(ctx, hipMemcpy(ctx->scene_dev, flat.get(), sizeof(crt::DevScene), hipMemcpyHostToDevice));
+    ctx->scene_host = *flat;
     ctx->has_scene = true;
     return CRT_OK;
 }

@@ -272,6 +272,54 @@ DI void sincos_c(float a, float& s, float& c) {
     }
 }
 
+// ------------------------------------------------------------------------ pow
+// Stand-in for __powf(x, y) with x >= 0 in the point light's Blinn-Phong term (Light.hpp:173):
+// exp2(y * log2(x)) out of IEEE operations in a fixed order (log2 from the atanh series of (m-1)/(m+1) on
+// m in (sqrt(1/2), sqrt(2)], exp2 from the degree-7 Taylor polynomial on [-1/2, 1/2]), so that the host
+// checker reproduces it bit for bit.  Relative error about 1e-7 * (1 + |y log2 x|); results below 2^-126
+// are flushed to zero.
+DI float pow_c(float x, float y) {
+    if (y == 0.0f) return 1.0f;
+    if (x != x || y != y) return x + y;
+    if (!(x > 0.0f)) return y > 0.0f ? 0.0f : __builtin_inff();
+    if (x > 3.0e38f) return y > 0.0f ? __builtin_inff() : 0.0f;
+    int e = 0;
+    if (x < 1.17549435e-38f) { // subnormal base
+        x = x * 16777216.0f;
+        e = -24;
+    }
+    uint32_t bits = __float_as_uint(x);
+    e += (int)(bits >> 23) - 127;
+    float m = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    const float sr = (m - 1.0f) / (m + 1.0f);
+    const float z = sr * sr;
+    float p = 0.111111112f;
+    p = 0.142857149f + z * p;
+    p = 0.2f + z * p;
+    p = 0.333333343f + z * p;
+    p = 1.0f + z * p;
+    const float lg = (float)e + ((2.0f * sr) * p) * 1.44269502f;
+    const float t = y * lg;
+    if (!(t < 128.0f)) return __builtin_inff();
+    if (t < -126.0f) return 0.0f;
+    const float nf = __builtin_floorf(t + 0.5f);
+    const float q = (t - nf) * 0.693147182f;
+    float w = 1.98412701e-4f;
+    w = 1.38888892e-3f + q * w;
+    w = 8.33333377e-3f + q * w;
+    w = 4.16666679e-2f + q * w;
+    w = 0.166666672f + q * w;
+    w = 0.5f + q * w;
+    w = 1.0f + q * w;
+    w = 1.0f + q * w;
+    const int n = (int)nf, n1 = n / 2, n2 = n - n1;
+    return (w * __uint_as_float((uint32_t)(n1 + 127) << 23)) * __uint_as_float((uint32_t)(n2 + 127) << 23);
+}
+
 // ------------------------------------------------------------ intersection tests
 // Sphere::hit (Sphere.hpp:40-98): returns the accepted root in t.  dd = d.d.
 DI bool sphere_t(V3 center, float radius_sq, V3 o, V3 d, float dd, float dist, float& t) {

@@ -109,7 +109,7 @@ DI V4 point_light_color(ScenePtr sc, const DevLight CRT_CONST* L, const DevGeomS
     float diff = max_std(dot3(N, lightDir), 0.0f);
     V3 diffuse = (lcol * (mk3(g->diffuse[0], g->diffuse[1], g->diffuse[2]) * diff)) * L->intensity;
     V3 halfway = normalize3(lightDir + view);
-    float spec = __builtin_powf(max_std(dot3(N, halfway), 0.0f), g->shininess);
+    float spec = pow_c(max_std(dot3(N, halfway), 0.0f), g->shininess);
     V3 specular = (lcol * (mk3(g->specular[0], g->specular[1], g->specular[2]) * spec)) * L->intensity;
     V3 result = (ambient + diffuse) + specular;
     return V4{result.x, result.y, result.z, 1.0f};

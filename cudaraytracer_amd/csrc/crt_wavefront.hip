@@ -2043,7 +2043,15 @@ void build_jump_table(uint32_t nsteps, uint32_t* tab) {
 
 } // namespace
 
-bool wavefront_supports(const RenderArgs&) { return true; }
+// A shade record's index shares a 32-bit word with its light (28 + 4 bits), and every pixel slot needs at
+// least 8 result slots plus its share of partly used record chunks per round: launches of more than about
+// 15 million pixel slots (for example 4096 x 4096) do not fit.
+bool wavefront_supports(const RenderArgs& a) {
+    const uint64_t n_lp = (uint64_t)a.n_units * 64u;
+    if (n_lp == 0) return true;
+    const uint64_t chunk_slack = (a.cooperative ? kCoopSplit : 1u) * 2u * kWorkChunk / 64u;
+    return ((1ull << 28) - 1u) / n_lp >= chunk_slack + 1u + 8u;
+}
 
 // Whether two launches map work units to pixels and rays the same way and walk trees of the same shape
 // (everything wf_cost_kernel reads, apart from the scene's contents).

@@ -154,6 +154,9 @@ public:
             if (s.renderAllAtOnce) {
                 check(crt_render(_ctx, &st, dev, nullptr), _ctx, "crt_render");
             } else {
+                // the window arithmetic below divides by the block shape; the ABI would refuse these, too
+                if (s.tx == 0 || s.ty == 0 || s.blocksPerDraw == 0)
+                    throw std::invalid_argument("tx, ty and blocksPerDraw must be positive");
                 const unsigned int blocksX = s.nx / s.tx + 1, blocksY = s.ny / s.ty + 1;
                 const unsigned int totalTiles = blocksX * blocksY;
                 for (unsigned int tileIndex = 0; tileIndex < totalTiles; tileIndex += s.blocksPerDraw)

@@ -224,7 +224,9 @@ int crt_scatter_shards(crt_ctx* ctx, uint32_t nx, uint32_t ny, uint32_t world,
 int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out);
 
 /* Which kernels crt_render / crt_render_partial / crt_render_shard run.  Both give the same bits.
- *   CRT_PIPELINE_AUTO        the wavefront pipeline (default)
+ *   CRT_PIPELINE_AUTO        the wavefront pipeline (default); the persistent kernel for launches the
+ *                            pipeline cannot hold (more than about 15 million pixels at once, e.g. 4096 x 4096,
+ *                            or no device memory left for its workspace)
  *   CRT_PIPELINE_PERSISTENT  one persistent kernel per launch, asynchronous on `stream`, no workspace
  *   CRT_PIPELINE_WAVEFRONT   trace / filter / resolve / shade / sum kernels with records in device
  *                            memory; the call returns after the image is complete (it synchronises

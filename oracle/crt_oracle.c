@@ -13,7 +13,8 @@
  * no fused contraction:
  *     __fdividef(a,b) -> a / b            rsqrtf(x) -> 1.0f / sqrtf(x)
  *     __saturatef(x)  -> fminf(fmaxf(x,0),1)
- *     __tanf/__powf   -> libm tanf/powf (per-camera / per-material constants)
+ *     __tanf/__powf   -> libm tanf/powf for the per-camera / per-material constants (evaluated on the host
+ *                        by the product as well); orc_pow() below for the point light's specular term
  *     __powf(x, 5)    -> ((x*x)*(x*x))*x in Schlick's reflectance (per glass hit; only compared with 1)
  *     __sinf/__cosf   -> orc_sincos() below (a fixed polynomial, so that CPU and
  *                        GPU can agree bit for bit; |err| < 2e-7)
@@ -179,6 +180,62 @@ void orc_sincos(float a, float* s, float* c) {
         case 2: *s = -sr; *c = -cr; break;
         default: *s = -cr; *c = sr; break;
     }
+}
+
+/* ------------------------------------------------------------------------- pow */
+/* Stand-in for __powf in the point light's Blinn-Phong term (Light.hpp:173): x >= 0 (the base is
+ * max(n.h, 0)).  __powf is exp2(y * log2(x)) in approximate device arithmetic that only CUDA reproduces; the
+ * canonical form here is the same composition out of IEEE operations in a fixed order -- log2 from the
+ * atanh series of (m-1)/(m+1) on m in (sqrt(1/2), sqrt(2)], exp2 from the degree-7 Taylor polynomial on
+ * [-1/2, 1/2] -- so that CPU and GPU agree bit for bit.  Relative error about 1e-7 * (1 + |y log2 x|);
+ * results below 2^-126 are flushed to zero. */
+float orc_pow(float x, float y) {
+    if (y == 0.0f) return 1.0f;
+    if (x != x || y != y) return x + y;
+    if (!(x > 0.0f)) return y > 0.0f ? 0.0f : INFINITY;
+    if (x > 3.0e38f) return y > 0.0f ? INFINITY : 0.0f;
+    int e = 0;
+    if (x < 1.17549435e-38f) { /* subnormal base */
+        x = x * 16777216.0f;
+        e = -24;
+    }
+    uint32_t bits;
+    memcpy(&bits, &x, 4);
+    e += (int)(bits >> 23) - 127;
+    bits = (bits & 0x007fffffu) | 0x3f800000u;
+    float m;
+    memcpy(&m, &bits, 4);
+    if (m > 1.41421354f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    const float sr = (m - 1.0f) / (m + 1.0f);
+    const float z = sr * sr;
+    float p = 0.111111112f;
+    p = 0.142857149f + z * p;
+    p = 0.2f + z * p;
+    p = 0.333333343f + z * p;
+    p = 1.0f + z * p;
+    const float lg = (float)e + ((2.0f * sr) * p) * 1.44269502f;
+    const float t = y * lg;
+    if (!(t < 128.0f)) return INFINITY;
+    if (t < -126.0f) return 0.0f;
+    const float nf = floorf(t + 0.5f);
+    const float q = (t - nf) * 0.693147182f;
+    float w = 1.98412701e-4f;
+    w = 1.38888892e-3f + q * w;
+    w = 8.33333377e-3f + q * w;
+    w = 4.16666679e-2f + q * w;
+    w = 0.166666672f + q * w;
+    w = 0.5f + q * w;
+    w = 1.0f + q * w;
+    w = 1.0f + q * w;
+    const int n = (int)nf, n1 = n / 2, n2 = n - n1;
+    uint32_t b1 = (uint32_t)(n1 + 127) << 23, b2 = (uint32_t)(n2 + 127) << 23;
+    float s1, s2;
+    memcpy(&s1, &b1, 4);
+    memcpy(&s2, &b2, 4);
+    return (w * s1) * s2;
 }
 
 /* ------------------------------------------------------------------------- RNG */
@@ -612,7 +669,7 @@ static v4 point_calculate_color(const ctx_t* cx, const crt_light* L, const light
     v3 mspec = V3(in->mat->specular[0], in->mat->specular[1], in->mat->specular[2]);
     v3 diffuse = v3_scale(v3_mul(lcol, v3_scale(mdiff, diff)), intensity);
     v3 halfway = v3_normalize(v3_add(lightDir, in->viewDir));
-    float spec = powf(max_std(v3_dot(in->norm, halfway), 0.0f), in->mat->shininess);
+    float spec = orc_pow(max_std(v3_dot(in->norm, halfway), 0.0f), in->mat->shininess);
     v3 specular = v3_scale(v3_mul(lcol, v3_scale(mspec, spec)), intensity);
     v3 result = v3_add(v3_add(ambient, diffuse), specular);
     return V4(result.x, result.y, result.z, 1.0f);

@@ -46,6 +46,9 @@ int orc_render(const crt_scene_desc* sc, const crt_settings* st, uint64_t seed, 
                float* fb, uint32_t* rng_inout6, int fresh_rng, uint32_t x0, uint32_t y0, uint32_t x1,
                uint32_t y1, int nthreads, orc_counters* total);
 
+/* Canonical stand-in for __powf(x, y), x >= 0 (the point light's specular term, Light.hpp:173). */
+float orc_pow(float x, float y);
+
 /* Function-level probes. */
 int orc_camera_ray(const crt_camera* cam, float x, float y, float w, float h, float o[3], float d[3]);
 int orc_world_hit(const crt_scene_desc* sc, const float o[3], const float d[3], float maxdist, orc_hit_record* out);

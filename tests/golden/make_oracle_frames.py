@@ -24,10 +24,18 @@ import cudaraytracer_amd as crt  # noqa: E402
 from frame_digest import BAND, digest  # noqa: E402
 
 
-CASES = {  # name: (image side, aa_iter, gl_iter); ref_iter 4, ind_rays 75, 50 shadow samples, seed 1234
-    "cornell_720_gl1": (720, 1, 1),     # the benchmark workload, three minutes on 8 cores
-    "cornell_128_gl2": (128, 1, 2),     # two GI levels: ~22 000 shaded points per pixel, many pipeline rounds
-    "cornell_256_aa3_gl1": (256, 3, 1), # adaptive anti-aliasing three levels deep on top of one GI level
+CASES = {  # name: (image side, aa_iter, gl_iter, shadowSamples); ref_iter 4, ind_rays 75, seed 1234
+    "cornell_720_gl1": (720, 1, 1, 50),     # the benchmark workload, three minutes on 8 cores
+    "cornell_128_gl2": (128, 1, 2, 50),     # two GI levels: ~22 000 shaded points per pixel, many pipeline rounds
+    "cornell_256_aa3_gl1": (256, 3, 1, 50), # adaptive anti-aliasing three levels deep on top of one GI level
+    # BASELINE's last configuration in miniature: aa_iter 4 over gl_iter 3 with ind_rays 75, i.e. the 128-entry
+    # stack truncation three levels deep under nested anti-aliasing tasks; 5e7 shaded points per pixel, so 36
+    # pixels and 4 shadow samples keep it at ten minutes on 8 cores
+    "cornell_6_aa4_gl3": (6, 4, 3, 4),
+    # the two halves of that configuration at sizes every trace mode finishes in seconds (a lane walks a
+    # pixel's tree step by step: 6.5e5 and 1.9e6 steps per pixel here, 5.5e7 above)
+    "cornell_12_gl3": (12, 1, 3, 4),       # ind_rays 75 three levels deep: 54 children at level 1, then 1..21 at level 2
+    "cornell_4_aa4_gl2": (4, 4, 2, 4),     # 340 color() calls per pixel over the truncated two-level tree
 }
 
 
@@ -35,12 +43,12 @@ def main():
     path = HERE / "oracle_full_frames.json"
     out = json.loads(path.read_text()) if path.exists() else {}
     for name in (sys.argv[1:] or list(CASES)):
-        n, aa, gl = CASES[name]
-        st = crt.make_settings(nx=n, ny=n, aa_iter=aa, gl_iter=gl)
+        n, aa, gl, S = CASES[name]
+        st = crt.make_settings(nx=n, ny=n, aa_iter=aa, gl_iter=gl, shadowSamples=S)
         t0 = time.perf_counter()
-        fb, cnt, state = O.render(O.cornell(50), st, 1234, want_state=True)
+        fb, cnt, state = O.render(O.cornell(S), st, 1234, want_state=True)
         d = digest(fb, state)
-        d.update({"nx": n, "ny": n, "aa_iter": aa, "gl_iter": gl, "seed": 1234, "band_rows": BAND,
+        d.update({"nx": n, "ny": n, "aa_iter": aa, "gl_iter": gl, "shadowSamples": S, "seed": 1234, "band_rows": BAND,
                   "rng_draws": int(cnt.rng_draws), "shade_points": int(cnt.shade_points),
                   "gi_children": int(cnt.gi_children),
                   "mean_rgba": [float(x) for x in fb.reshape(-1, 4).astype(np.float64).mean(0)]})

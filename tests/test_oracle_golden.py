@@ -56,6 +56,24 @@ def test_sincos_accuracy(oracle):
     assert worst < 2e-7
 
 
+def test_canonical_pow_accuracy(oracle):
+    """orc_pow stands in for __powf in the point light's specular term: exp2(y log2 x) from fixed polynomials."""
+    L = oracle.lib()
+    L.orc_pow.restype = C.c_float
+    L.orc_pow.argtypes = [C.c_float, C.c_float]
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for x, y in zip(rng.uniform(0.0, 1.0, 4000).astype(np.float32), rng.uniform(0.0, 64.0, 4000).astype(np.float32)):
+        want = float(np.float64(x) ** np.float64(y))
+        got = L.orc_pow(float(x), float(y))
+        if want > 1e-30:
+            worst = max(worst, abs(got / want - 1.0) / (1.0 + abs(float(y) * np.log2(max(float(x), 1e-30)))))
+    assert worst < 3e-7
+    assert L.orc_pow(0.0, 5.0) == 0.0 and L.orc_pow(0.0, 0.0) == 1.0 and L.orc_pow(0.37, 0.0) == 1.0
+    assert L.orc_pow(1.0, 123.0) == 1.0 and L.orc_pow(0.5, 2.0) == 0.25 and L.orc_pow(2.0, 10.0) == 1024.0
+    assert L.orc_pow(1e-30, 8.0) == 0.0 and np.isinf(L.orc_pow(0.0, -1.0))
+
+
 def test_cornell_scene_constants(oracle):
     sc = oracle.cornell(50)
     light = sc.lights[0]

@@ -41,8 +41,7 @@ for seed in range(first, first + count):
     checked, bad = ctx.audit_result()
     ctx.close()
     ref, _, ref_state = oracle_lib.render(random_scene(oracle_lib, seed, S, wild), st, seed, want_state=True)
-    point = any(l.kind == abi.CRT_LIGHT_POINT for l in scene.lights)
-    same = np.abs(fb - ref).max() <= 1e-5 if point else np.array_equal(fb, ref)
+    same = np.array_equal(fb, ref)
     ok = bad == 0 and same and np.array_equal(state, ref_state)
     if not ok:
         failures += 1
