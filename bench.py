@@ -56,9 +56,93 @@ def cpu_baseline(workload_gl, budget_s):
     _, cnt, _ = O.render(sc, st, 1234, region=(x0, x0, x0 + crop, x0 + crop), threads=threads)
     dt = time.perf_counter() - t0
     shadow = (cnt.rng_draws - 2 * cnt.gi_children) // 2
+    model, physical = "unknown", set()
+    try:
+        phys = core = None
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "model name":
+                model = val
+            elif key == "physical id":
+                phys = val
+            elif key == "core id":
+                core = val
+            elif not key and phys is not None:
+                physical.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
     return {"value": shadow / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "host": {"cpu_model": model, "logical_cpus": os.cpu_count(), "physical_cores": len(physical) or None,
+                     "threads_used": threads},
             "sample": f"centred {crop}x{crop} crop of the 720x720 gl_iter={workload_gl} render, seed 1234, "
                       f"{shadow} shadow samples in {dt:.2f} s (OpenMP, dynamic rows)"}
+
+
+def config5(args, torch, crt):
+    """BASELINE's last configuration: 720x720, aa_iter 4, gl_iter 3, ind_rays 75, 50 shadow samples, 8 GPUs.
+    The whole frame is about 2.5e13 shaded points -- two hours of one GPU -- so it is measured in parts, all on
+    this GPU, and put together:
+      work   shaded points of the frame = points(aa_iter 1, gl_iter 3) x points(aa_iter 4, gl_iter 1) /
+             points(aa_iter 1, gl_iter 1): the first is the README's 6 h 24 min row rendered in full, the ratio is
+             the number of color() calls adaptive anti-aliasing makes per pixel, 4 at aa_iter 1 (it does not
+             depend on gl_iter as long as gl_iter >= 1: the GI noise makes every colour comparison fail);
+      rate   what one rank of eight launches -- crt_render_shard(rank 0 of 8), 64 800 pixels in interleaved 8x8
+             tiles -- timed over its first --c5-rounds pipeline rounds (CRT_WF_MAX_ROUNDS), with the GPU as full as
+             it is in the real job (the end of the frame, where few pixels are left, is not in the sample).
+    Reported: the rate in Msamples/s, and work / 8 / rate as the time eight GPUs would need."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    stream = torch.cuda.current_stream(dev)
+    nx = ny = 720
+    points = {}
+    with crt.Context(0) as ctx:
+        ctx.upload(crt.cornell_box(50))
+        fb = torch.empty((ny, nx, 4), dtype=torch.float32, device=dev)
+        for aa, gl in ((1, 1), (4, 1), (1, 3)):
+            st = crt.make_settings(nx=nx, ny=ny, aa_iter=aa, gl_iter=gl)
+            ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
+            t0 = time.perf_counter()
+            ctx.render(st, fb.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            points[(aa, gl)] = {"shade_points": int(ctx.stats(st).shade_points), "s": time.perf_counter() - t0}
+            print(f"# aa_iter {aa} gl_iter {gl}: {points[(aa, gl)]}", file=sys.stderr, flush=True)
+    calls_ratio = points[(4, 1)]["shade_points"] / points[(1, 1)]["shade_points"]
+    frame_points = points[(1, 3)]["shade_points"] * calls_ratio
+    st = crt.make_settings(nx=nx, ny=ny, aa_iter=4, gl_iter=3)
+    os.environ["CRT_WF_MAX_ROUNDS"] = str(args.c5_rounds)
+    try:
+        with crt.Context(0) as ctx:
+            ctx.upload(crt.cornell_box(50))
+            ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
+            n = crt.shard_tiles_max(nx, ny, 8) * 64 * 4
+            compact = torch.empty(n, dtype=torch.float32, device=dev)
+            ctx.reserve_workspace(st, 0, 8)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            ctx.render_shard(st, 0, 8, compact.data_ptr(), stream.cuda_stream)  # unfinished on purpose
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            done = int(ctx.stats(st).shade_points)
+    finally:
+        del os.environ["CRT_WF_MAX_ROUNDS"]
+    rate = done / dt
+    est_s = frame_points / 8 / rate
+    print(json.dumps({
+        "metric": "Cornell 720x720 aa_iter=4 gl_iter=3 (BASELINE configs[4]): shadow-sample throughput of one rank of 8, "
+                  "extrapolated render time on 8 GPUs",
+        "value": rate * 50 / 1e6, "unit": "Msamples/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f32",
+        "data": "synthetic", "vs_baseline": None,
+        "config": {"workload": "Cornell box 720x720, aa_iter=4, ref_iter=4, gl_iter=3, ind_rays=75, shadowSamples=50",
+                   "sampling": f"rank 0 of 8 (interleaved 8x8 tiles, 64 800 pixels), first {args.c5_rounds} pipeline rounds: "
+                               f"{done} shaded points in {dt:.2f} s",
+                   "seed": args.seed},
+        "frame_shade_points": frame_points, "color_calls_per_pixel": 4 * calls_ratio,
+        "extrapolated_s_on_8_gpus": est_s, "extrapolated_s_on_1_gpu": frame_points / rate,
+        "parts": {f"aa{aa}_gl{gl}": v for (aa, gl), v in points.items()},
+        "readme_aa1_gl3_rtx4070tis_s": README_4070TIS_S["gl3"],
+    }), flush=True)
 
 
 def main():
@@ -66,8 +150,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["gl0", "gl1", "gl2", "gl3"], default="gl1",
-                    help="README benchmark row; gl3 takes about 80 s per step on one GPU")
+    ap.add_argument("--workload", choices=["gl0", "gl1", "gl2", "gl3", "c5"], default="gl1",
+                    help="README benchmark row; gl3 takes about 80 s per step on one GPU; c5 = BASELINE's last "
+                         "configuration (aa_iter 4, gl_iter 3), measured on a sample and extrapolated (minutes)")
+    ap.add_argument("--c5-rounds", type=int, default=24, help="pipeline rounds timed by --workload c5")
     ap.add_argument("--nx", type=int, default=720)
     ap.add_argument("--ny", type=int, default=720)
     ap.add_argument("--seed", type=int, default=1234)
@@ -95,6 +181,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.workload == "c5":
+        return config5(args, torch, crt)
     gl = int(args.workload[2])
     nx, ny = args.nx, args.ny
     st = crt.make_settings(nx=nx, ny=ny, gl_iter=gl)
@@ -165,11 +253,12 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         per_launch = {k: v / args.steps for k, v in work.items()}
         achieved = algorithmic_flops(per_launch) / (kernel_ms * 1e-3) / 1e12
-        traffic = None
+        traffic = traffic_from = None
         tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
+        if tfile.exists():  # PMC passes are separate rocprofv3 runs (tools/prof_traffic.sh); the line quotes their result
             try:
-                traffic = json.loads(tfile.read_text()).get(f"{args.workload}_n{world}_{nx}x{ny}", {}).get("hbm_bytes_per_launch")
+                entry = json.loads(tfile.read_text()).get(f"{args.workload}_n{world}_{nx}x{ny}", {})
+                traffic, traffic_from = entry.get("hbm_bytes_per_launch"), entry.get("profile")
             except Exception:
                 traffic = None
         out = {
@@ -191,7 +280,7 @@ def main():
                        if world > 1 else "none",
                        "primary_samples_per_s": nx * ny * 4 / (elapsed / args.steps)},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_profile": traffic_from,
                          "kernel": ("wavefront pipeline (" + "+".join(ktimes) + ")") if ktimes else "crt::render_kernel",
                          "kernel_ms": kernel_ms, "render_call_ms": render_ms,
                          "kernels": {k: {"ms": ms, "launches": n} for k, (ms, n) in ktimes.items()},

@@ -40,13 +40,15 @@ enum WfKernel : uint32_t { WF_K_TRACE = 0, WF_K_FILTER, WF_K_RESOLVE, WF_K_SHADE
 struct WfWorkspace {
     uint32_t n_lp = 0;      // pixel slots (work units * 64) the planes are sized for
     uint32_t quota = 0;     // result slots a pixel may fill per round
+    bool single_round = false; // every pixel finishes within one round (quota covers its whole tree, aa_iter <= 1)
     uint32_t gl_levels = 0; // frame levels allocated
     uint32_t cap_work = 0;  // shade records per round
     uint32_t n_lights = 0;  // shadow-count planes
-    uint32_t qcap = 0;      // unresolved shadow rays per filter batch
+    uint32_t qcap = 0;      // undecided shadow rays the queue holds
     uint32_t max_shadow_rays = 0; // shadow rays per record the queue was sized for
-    uint32_t* ctrs = nullptr;       // device counters (WF_CTR_*), 64 words
-    uint32_t* ctrs_host = nullptr;  // pinned mirror
+    uint32_t npix = 0;      // pixels of the image the generator backup is sized for
+    uint32_t* ctrs = nullptr;       // device counters (WF_CTR_*)
+    uint32_t* ctrs_host = nullptr;  // pinned mirror: WF_CTR_RING copies, one per round in flight
     uint32_t* state = nullptr;      // [WF_STATE_PLANES][n_lp] traversal state between rounds
     uint32_t* frames = nullptr;     // [gl_levels][WF_FRAME_PLANES][n_lp]
     uint8_t* tags = nullptr;        // [quota][n_lp]
@@ -59,20 +61,23 @@ struct WfWorkspace {
     uint32_t* queue = nullptr;      // [3][qcap]
     uint32_t* jump_dev = nullptr;   // two generator jump tables
     uint32_t jump_n[2] = {0, 0};    // step counts the tables were built for
-    uint32_t* qcounts = nullptr;    // entries per filter wave
     uint32_t* unit_cost = nullptr;  // [n_units] cost estimate per work unit (float bits)
     uint32_t* unit_order = nullptr; // [n_units] launch order of the trace kernel
     uint32_t* unit_host = nullptr;  // pinned: [n_units] costs, then [n_units] order
     bool order_valid = false;       // unit_order holds the order for order_key (same scene upload)
     RenderArgs order_key{};         // launch whose order unit_order holds: the estimate depends on scene, camera and pixel mapping only
+    uint32_t* backup = nullptr;     // [8][npix] + 8 words: generator states, work counters and wave tallies as they were
+                                    // when the frame started (a frame whose ray queue overflows is rendered again)
+    void* round_events = nullptr;   // hipEvent_t[WF_CTR_RING]: the counter copy of round r has landed
     // cooperative trace only
     float* draws = nullptr;         // [2 * CRT_RAY_STACK][n_lp]: the (r1, r2) pairs of the innermost node's children
-    uint32_t* coop_tabs = nullptr;  // 14 jump tables: 1..7 and 8, 16, .., 56 shaded points' worth of draws
+    uint32_t* coop_tabs = nullptr;  // 63 jump tables: 1..63 shaded points' worth of draws
     uint32_t coop_n = 0xffffffffu;  // draws per shaded point the tables were built for
     void* side_stream = nullptr;    // hipStream_t: the cooperative kernel of a mixed launch runs here
     void* fork_event = nullptr;     // hipEvent_t pair ordering the side stream against the caller's
     void* join_event = nullptr;
     size_t bytes = 0;
+    uint64_t frames_redone = 0;     // frames rendered a second time because the ray queue overflowed
     // optional per-kernel timing with HIP events on the launch stream (crt_set_timing)
     bool timing = false;
     void* timer = nullptr;   // event pool, owned by crt_wavefront.hip
@@ -80,11 +85,13 @@ struct WfWorkspace {
     uint64_t kernel_launches[WF_KERNEL_COUNT] = {0};
 };
 constexpr uint32_t WF_STATE_PLANES = 49, WF_FRAME_PLANES = 19, WF_WORK_PLANES = 21;
+constexpr uint32_t WF_CTR_RING = 4;
 enum WfCounter : uint32_t {
-    WF_CTR_WORK = 0,    // shade records emitted this round
+    WF_CTR_WORK = 0,    // record indices handed out this round
     WF_CTR_ACTIVE = 1,  // pixels not finished after this round
-    WF_CTR_QOVERFLOW = 3, // a filter wave ran out of queue space in an optimistically sized launch (cleared per round)
-    WF_CTR_ERROR = 5,   // non-zero: a capacity was exceeded (results invalid)
+    WF_CTR_QUEUE = 2,   // undecided shadow rays queued by the filter kernel (cleared per round, or per filter batch)
+    WF_CTR_ERROR = 5,   // non-zero: a capacity was exceeded (results invalid); sticky for the frame
+    WF_CTR_QOVERFLOW = 6, // non-zero: the ray queue was full and rays were dropped; sticky for the frame
     WF_CTR_COUNT = 16,
 };
 // True when the wavefront pipeline implements these settings (all of them).
@@ -92,8 +99,11 @@ bool wavefront_supports(const RenderArgs& args);
 // Frees / (re)allocates the workspace for this launch; returns hipSuccess or the allocation error.
 hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n_lights, size_t budget_bytes);
 void wavefront_release(WfWorkspace& ws);
-// Runs the pipeline on `stream`; synchronises the stream once per round.  *overflow is set when a
-// capacity check on the device failed.
+// Runs the pipeline on `stream`.  Rounds are queued without waiting for each other; the call waits for the
+// frame's end to read the device's error flags, except for launches that need one round and cannot
+// overflow the ray queue (gl_iter 0 at aa_iter <= 1), which are left running on `stream`.  A frame whose
+// ray queue overflowed is rendered again from the saved generator states with launches sized for the worst
+// case.  *overflow is set when a capacity check on the device failed for good.
 hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow);
 
 void launch_random_init(uint32_t npix, uint64_t seed, uint32_t* state, hipStream_t stream);

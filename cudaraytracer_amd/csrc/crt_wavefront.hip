@@ -32,6 +32,8 @@
 // reference, so results are bit-identical to the single-kernel path in crt_render.hip.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -49,9 +51,8 @@ enum : uint32_t { TAG_ADD = 0, TAG_END_CALL = 1, TAG_END_PIXEL = 2 };
 enum : uint32_t { AA_PENDING = 0, AA_ALL_EQUAL = 1, AA_SUBDIVIDE = 2 };
 constexpr uint32_t kWorkChunk = 256;         // shade-record indices a trace wave reserves at a time
 constexpr uint32_t kMaxFilterWaves = 16384;   // upper bound of the filter kernel's grid
-constexpr uint32_t kOptimism = 8;            // first filter attempt: records per launch relative to the worst-case bound
-constexpr uint32_t kResolveSplit = 8;        // resolve waves per filter wave's queue region
 constexpr uint32_t kNoRecord = 0xffffffffu;  // primitive index of an unused record slot
+constexpr uint32_t kFromCounter = 0xffffffffu; // kernel argument: take the record count from WF_CTR_WORK
 
 // state planes
 enum : uint32_t {
@@ -82,8 +83,7 @@ struct WfArgs {
     const uint32_t* jump_tabs; // two rng_jump tables: [0] for jump_n[0] = draws per shaded point, [1] for jump_n[1] = 2 ind_rays
     uint32_t jump_n[2];        // 0: no table
     uint32_t* queue;
-    uint32_t* qcounts;    // entries each filter wave left in its region of the queue
-    uint32_t region_cap;  // queue entries per filter wave
+    uint32_t qchunk;           // queue entries a filter wave reserves at a time (a multiple of 64)
     const uint32_t* unit_order; // trace: launch slot -> work unit, most expensive first; null = identity
     float* draws;              // cooperative trace: [2 * CRT_RAY_STACK][n_lp] child draws of the innermost leaf node
     const uint32_t* coop_tabs; // cooperative trace: kCoopTables rng_jump tables in device memory, table k-1 jumps k shaded points' worth of draws
@@ -132,16 +132,27 @@ constexpr uint32_t kStageCap = 128; // < 64 left over + 64 new entries per appen
 struct Stage {
     uint32_t head, fill; // wave-uniform ring cursor
     uint32_t written;    // entries already moved to the queue
+    uint32_t q_next, q_end; // the wave's piece of the queue: next free entry, end (q_next == q_end: none)
 };
+constexpr uint32_t kNoRay = 0xffffffffu; // queue key of an entry that holds no ray
 
-// Moves `n` staged entries (n <= 64) to this wave's region of the queue.
+// Moves `n` staged entries (n <= 64) to the queue.  A wave reserves the queue in pieces of w.qchunk entries
+// (one atomic on the device counter per piece: atomics on one address are served one after the other, about
+// 9 ns each, which at one per 64 rays was three times the kernel's own time); what it leaves unused of its
+// last piece is marked "no ray" by stage_close.  When the queue is full the rays are dropped and the frame is
+// marked (the host renders it again with launches sized for the worst case).
 DI void stage_flush(const WfArgs& w, uint32_t (*stg)[kStageCap], Stage& st, uint32_t n, uint32_t lane) {
     __syncthreads();
+    if (st.q_next == st.q_end) { // pieces are multiples of 64 and flushes before the last one are 64: no straddling
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(&w.ctrs[WF_CTR_QUEUE], w.qchunk);
+        st.q_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        st.q_end = st.q_next + w.qchunk;
+    }
     if (lane < n) {
         const uint32_t pos = (st.head + lane) & (kStageCap - 1u);
-        const uint32_t k = st.written + lane;
-        if (k < w.region_cap) {
-            const size_t idx = (size_t)blockIdx.x * w.region_cap + k;
+        const uint32_t idx = st.q_next + lane;
+        if (idx < w.qcap && st.q_end > st.q_next) { // (q_end < q_next: the 32-bit counter wrapped)
             w.queue[idx] = stg[0][pos];
             w.queue[(size_t)w.qcap + idx] = stg[1][pos];
             w.queue[2 * (size_t)w.qcap + idx] = stg[2][pos];
@@ -149,10 +160,18 @@ DI void stage_flush(const WfArgs& w, uint32_t (*stg)[kStageCap], Stage& st, uint
             w.ctrs[WF_CTR_QOVERFLOW] = 1u;
         }
     }
+    st.q_next += n;
     st.head = (st.head + n) & (kStageCap - 1u);
     st.fill -= n;
     st.written += n;
     __syncthreads();
+}
+// End of the kernel: the last entries, then "no ray" marks on the rest of the wave's piece.
+DI void stage_close(const WfArgs& w, uint32_t (*stg)[kStageCap], Stage& st, uint32_t lane) {
+    if (st.fill != 0u) stage_flush(w, stg, st, st.fill, lane);
+    if (st.q_end > st.q_next)
+        for (uint32_t idx = st.q_next + lane; idx < st.q_end; idx += 64u)
+            if (idx < w.qcap) w.queue[idx] = kNoRay;
 }
 
 // Conservative classification of NB shadow rays of one shaded point against the primitives in
@@ -1569,16 +1588,19 @@ DI void filter_batch(const WfArgs& w, ScenePtr sc, uint32_t li, const LightF& lf
 // lanes busy); records whose samples have to be looked at are compacted through an LDS queue, and the
 // sample loop runs on full batches of 64 of them.
 // ORDINALS: the records may come from the cooperative trace kernel (see kCoopBatch).
+// w_end == kFromCounter: all records of the round (the count is read from the device counter, so the host
+// does not have to know it).
 template <bool ORDINALS>
 __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end) {
     ScenePtr sc = (ScenePtr)w.r.scene;
     const uint32_t lane = threadIdx.x;
     __shared__ uint32_t stg[3][kStageCap];
     __shared__ uint32_t rq[11][kRecQueueCap]; // record index, P, generator state (draws_before steps after the record's), the record's ordinal
-    Stage st = {0u, 0u, 0u};
+    Stage st = {0u, 0u, 0u, 0u, 0u};
     uint32_t rqn = 0; // wave-uniform fill of rq
     uint32_t tally = 0;
     const size_t cw = w.cap_work;
+    if (w_end == kFromCounter) w_end = min(w.ctrs[WF_CTR_WORK], w.cap_work);
     const uint32_t n_lights = sc->n_lights;
     uint32_t draws_before = 0; // draws of one record that precede light li (AreaLight.hpp:342-343 per sample)
     for (uint32_t li = 0; li < n_lights; ++li) {
@@ -1586,7 +1608,7 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
         if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue; // no draws (Light.hpp:92-111, AreaLight.hpp:586)
         const uint32_t S = L->shadow_samples;
         const LightF lf = load_lightf(L);
-        for (uint32_t base = blockIdx.x * 64u; base < w_end - w_begin; base += gridDim.x * 64u) {
+        for (uint32_t base = blockIdx.x * 64u; w_begin < w_end && base < w_end - w_begin; base += gridDim.x * 64u) {
             const uint32_t wi = w_begin + base + lane;
             const uint32_t wr = wi < w_end ? wi : w_begin;
             const uint32_t gword = w.work[(size_t)WK_GEOM * cw + wr];
@@ -1627,8 +1649,7 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
         while (rqn != 0u) filter_batch<ORDINALS>(w, sc, li, lf, S, rq, rqn, stg, st, lane, tally);
         draws_before += 2u * S;
     }
-    if (st.fill != 0u) stage_flush(w, stg, st, st.fill, lane);
-    if (lane == 0) w.qcounts[blockIdx.x] = st.written;
+    stage_close(w, stg, st, lane);
     if (lane == 0 && tally != 0u) atomicAdd(&w.r.wave_tallies[0], (unsigned long long)tally);
 }
 
@@ -1642,7 +1663,8 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
     const size_t cw = w.cap_work;
     const uint32_t n_lights = sc->n_lights;
     unsigned long long decided = 0, bad = 0;
-    for (uint32_t base = blockIdx.x * 64u; base < w_end - w_begin; base += gridDim.x * 64u) {
+    if (w_end == kFromCounter) w_end = min(w.ctrs[WF_CTR_WORK], w.cap_work);
+    for (uint32_t base = blockIdx.x * 64u; w_begin < w_end && base < w_end - w_begin; base += gridDim.x * 64u) {
         const uint32_t wi = w_begin + base + lane;
         const uint32_t wr = wi < w_end ? wi : w_begin;
         const uint32_t gword = w.work[(size_t)WK_GEOM * cw + wr];
@@ -1766,23 +1788,24 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
     __shared__ float gq_f[9][kGlassCap];    // origin, direction, first hit (t, u, v)
     __shared__ uint32_t gq_u[2][kGlassCap]; // queue key (record | light << 28), primitive
     uint32_t gq = 0;                        // wave-uniform fill
-    // kResolveSplit waves share one filter wave's region, taking every kResolveSplit-th group of 64 rays
-    const uint32_t reg = blockIdx.x / kResolveSplit, part = blockIdx.x % kResolveSplit;
-    const uint32_t qcount = min(w.qcounts[reg], w.region_cap);
-    const size_t region = (size_t)reg * w.region_cap;
+    // the queue's fill is whatever the filter kernel left in the device counter
+    const uint32_t qcount = min(w.ctrs[WF_CTR_QUEUE], w.qcap);
     uint32_t glass_tally = 0;
-    for (uint32_t base = part * 64u; base < qcount; base += kResolveSplit * 64u) {
-        const bool act = base + lane < qcount;
-        const size_t idx = region + base + lane;
+    for (uint32_t base = blockIdx.x * 64u; base < qcount; base += gridDim.x * 64u) {
+        bool act = base + lane < qcount;
+        const size_t idx = (size_t)base + lane;
         uint32_t key = 0;
         float u = 0.0f, v = 0.0f;
         V3 P = mk3(0, 0, 0);
+        if (act) key = w.queue[idx];
+        act = act && key != kNoRay;
         if (act) {
-            key = w.queue[idx];
             u = u2f(w.queue[(size_t)w.qcap + idx]);
             v = u2f(w.queue[2 * (size_t)w.qcap + idx]);
             const uint32_t* r = w.work + (key & 0x0fffffffu);
             P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
+        } else {
+            key = 0u;
         }
         const uint32_t my_light = key >> 28;
         bool glass = false;
@@ -1833,10 +1856,15 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
 }
 
 // ---------------------------------------------------------------------------------------- shade
-__global__ void __launch_bounds__(64, 4) wf_shade_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end) {
-    ScenePtr sc = (ScenePtr)w.r.scene;
-    const uint32_t wi = w_begin + blockIdx.x * 64u + threadIdx.x;
-    if (wi >= w_end) return;
+// One block per 64 records; the grid covers the workspace's capacity and blocks beyond the round's record
+// count (read from the device counter) leave at once.
+DI void shade_record(const WfArgs& w, ScenePtr sc, uint32_t wi);
+__global__ void __launch_bounds__(64, 4) wf_shade_kernel(WfArgs w) {
+    const uint32_t wi = blockIdx.x * 64u + threadIdx.x;
+    if (wi >= min(w.ctrs[WF_CTR_WORK], w.cap_work)) return;
+    shade_record(w, (ScenePtr)w.r.scene, wi);
+}
+DI void shade_record(const WfArgs& w, ScenePtr sc, uint32_t wi) {
     const size_t cw = w.cap_work;
     const uint32_t* r = w.work + wi;
     const V3 P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
@@ -2040,6 +2068,36 @@ void build_jump_table(uint32_t nsteps, uint32_t* tab) {
             }
     }
 }
+// Table of "jump a, then jump b": every entry of table a, itself a generator state, is put through table b.
+void compose_jump_tables(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    for (uint32_t en = 0; en < kJumpEntries; ++en) {
+        const uint32_t in[5] = {a[4u * en], a[4u * en + 1u], a[4u * en + 2u], a[4u * en + 3u], a[4u * kJumpEntries + en]};
+        uint32_t o[5] = {0, 0, 0, 0, 0};
+        for (uint32_t wd = 0; wd < 5u; ++wd)
+            for (uint32_t nb = 0; nb < 8u; ++nb) {
+                const uint32_t idx = (wd * 8u + nb) * 16u + ((in[wd] >> (4u * nb)) & 15u);
+                for (uint32_t k = 0; k < 4u; ++k) o[k] ^= b[4u * idx + k];
+                o[4] ^= b[4u * kJumpEntries + idx];
+            }
+        for (uint32_t k = 0; k < 4u; ++k) out[4u * en + k] = o[k];
+        out[4u * kJumpEntries + en] = o[4];
+    }
+}
+
+// Result slots one pixel can fill without a break: per color() call one per popped ray that can end in a hit
+// or a miss (1 + ind + ind^2 + ..) and one end-of-call marker; one end-of-pixel marker.  Without a break a
+// pixel makes 1 (aa_iter 0) or 4 (aa_iter 1) color() calls, else a level-2 task's four subtasks of four calls
+// before it has to wait for a verdict on its colours.
+uint64_t slots_per_pixel(const RenderArgs& a) {
+    const uint64_t calls = a.aa_iter == 0u ? 1u : (a.aa_iter == 1u ? 4u : 16u);
+    uint64_t rays = 1, level = 1;
+    for (uint32_t g = 0; g < a.gl_iter && rays < (1ull << 32); ++g) {
+        level *= a.ind_rays;
+        rays += level;
+    }
+    return calls * (rays + 1u) + 1u;
+}
+constexpr uint32_t kMinQuota = 8;
 
 } // namespace
 
@@ -2050,7 +2108,7 @@ bool wavefront_supports(const RenderArgs& a) {
     const uint64_t n_lp = (uint64_t)a.n_units * 64u;
     if (n_lp == 0) return true;
     const uint64_t chunk_slack = (a.cooperative ? kCoopSplit : 1u) * 2u * kWorkChunk / 64u;
-    return ((1ull << 28) - 1u) / n_lp >= chunk_slack + 1u + 8u;
+    return ((1ull << 28) - 1u) / n_lp >= chunk_slack + 1u + kMinQuota;
 }
 
 // Whether two launches map work units to pixels and rays the same way and walk trees of the same shape
@@ -2077,50 +2135,50 @@ void wavefront_release(WfWorkspace& ws) {
     (void)hipFree(ws.shadow_cnt);
     (void)hipFree(ws.queue);
     (void)hipFree(ws.jump_dev);
-    delete static_cast<EventTimer*>(ws.timer);
-    (void)hipFree(ws.qcounts);
-    (void)hipFree(ws.draws);
     (void)hipFree(ws.coop_tabs);
+    (void)hipFree(ws.backup);
+    delete static_cast<EventTimer*>(ws.timer);
+    (void)hipFree(ws.draws);
     if (ws.side_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(ws.side_stream));
     if (ws.fork_event) (void)hipEventDestroy(static_cast<hipEvent_t>(ws.fork_event));
     if (ws.join_event) (void)hipEventDestroy(static_cast<hipEvent_t>(ws.join_event));
+    if (ws.round_events) {
+        hipEvent_t* ev = static_cast<hipEvent_t*>(ws.round_events);
+        for (uint32_t k = 0; k < WF_CTR_RING; ++k)
+            if (ev[k]) (void)hipEventDestroy(ev[k]);
+        delete[] ev;
+    }
     (void)hipFree(ws.unit_cost);
     (void)hipFree(ws.unit_order);
     (void)hipHostFree(ws.unit_host);
     const bool timing = ws.timing;
+    const uint64_t redone = ws.frames_redone;
     ws = WfWorkspace();
     ws.timing = timing;
+    ws.frames_redone = redone;
 }
 
 hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n_lights, size_t budget_bytes) {
     const uint32_t n_lp = args.n_units * 64u;
     if (n_lp == 0) return hipSuccess;
-    // Slots one pixel can fill in total: per color() call one per popped ray that can end in a hit or a
-    // miss (1 + ind + ind^2 + ...), one end-of-call marker; one end-of-pixel marker.
-    // color() calls a pixel can make before it has to wait for a verdict on its colours: 1 (aa_iter 0),
-    // 4 (aa_iter 1), else a level-2 task's four subtasks of four calls
-    const uint64_t calls = args.aa_iter == 0u ? 1u : (args.aa_iter == 1u ? 4u : 16u);
-    uint64_t rays = 1, level = 1;
-    for (uint32_t g = 0; g < args.gl_iter && rays < (1ull << 32); ++g) {
-        level *= args.ind_rays;
-        rays += level;
-    }
-    uint64_t want = calls * (rays + 1u) + 1u;
+    const uint32_t npix = args.nx * args.ny;
+    uint64_t want = slots_per_pixel(args);
     const uint32_t lights = n_lights ? n_lights : 1u;
     // bytes per pixel slot and quota unit: tag 1 + contribution 16 + shade record planes + shadow counts
     const uint64_t per_slot = 1u + 16u + 4u * WF_WORK_PLANES + 4u * lights;
     uint64_t quota_max = budget_bytes / (per_slot * n_lp);
-    if (quota_max < 16u) quota_max = 16u;
+    if (quota_max < 16u) quota_max = 16u; // what a round needs to make progress, whatever the limit says
     if (want > quota_max) want = quota_max;
     const uint64_t chunk_slack = (args.cooperative ? kCoopSplit : 1u) * 2u * kWorkChunk / 64u; // partly used chunks, per pixel slot
     if ((want + chunk_slack + 1u) * n_lp >= (1ull << 28)) { // record index and light share one word
-        want = ((1ull << 28) - 1u) / n_lp - chunk_slack - 1u;
-        if (want < 8u) return hipErrorOutOfMemory; // more than 2^25 pixel slots in one launch
+        const uint64_t room = ((1ull << 28) - 1u) / n_lp;
+        if (room < chunk_slack + 1u + kMinQuota) return hipErrorOutOfMemory; // see wavefront_supports
+        want = room - chunk_slack - 1u;
     }
     const uint32_t quota = (uint32_t)want;
     const uint32_t levels = args.gl_iter ? args.gl_iter : 1u;
     if (ws.n_lp == n_lp && ws.quota >= quota && ws.gl_levels >= levels && ws.n_lights >= lights &&
-        ws.max_shadow_rays >= args.max_shadow_rays && (!args.cooperative || ws.draws != nullptr))
+        ws.max_shadow_rays >= args.max_shadow_rays && ws.npix == npix && (!args.cooperative || ws.draws != nullptr))
         return hipSuccess;
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return e;
@@ -2128,9 +2186,9 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     // + every trace wave's two partly used chunks; a multiple of the chunk size so that both streams stay aligned
     const uint32_t trace_waves = args.cooperative ? args.n_units * kCoopSplit : args.n_units;
     const uint32_t cap_work = ((quota * n_lp + trace_waves * kWorkChunk + kWorkChunk - 1u) / kWorkChunk) * kWorkChunk;
-    // every filter wave owns a region of the queue that holds all shadow rays of its records:
-    // at most 2^30 rays (12.9 GB), less when all records of a round cast fewer
-    uint64_t qwant = (uint64_t)cap_work * (args.max_shadow_rays ? args.max_shadow_rays : 1u) + 64ull * kMaxFilterWaves;
+    // the queue of undecided shadow rays: room for every ray of a round if that is less than 2^30 rays
+    // (12.9 GB); normally a few per cent of the rays get there
+    uint64_t qwant = (uint64_t)cap_work * (args.max_shadow_rays ? args.max_shadow_rays : 1u);
     if (qwant > (1ull << 30)) qwant = 1ull << 30;
     if (qwant > budget_bytes / 36u) qwant = budget_bytes / 36u; // at most a third of the budget (12 B per ray)
     if (qwant < (1ull << 20)) qwant = 1ull << 20;
@@ -2141,7 +2199,7 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
         e = hipMalloc(p, bytes);
         total += bytes;
     };
-    grab((void**)&ws.ctrs, WF_CTR_COUNT * 16u * sizeof(uint32_t));
+    grab((void**)&ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t));
     grab((void**)&ws.state, (size_t)WF_STATE_PLANES * n_lp * 4u);
     grab((void**)&ws.frames, (size_t)levels * WF_FRAME_PLANES * n_lp * 4u);
     grab((void**)&ws.tags, (size_t)quota * n_lp);
@@ -2153,7 +2211,7 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     grab((void**)&ws.shadow_cnt, (size_t)lights * cap_work * 4u);
     grab((void**)&ws.queue, (size_t)3u * qcap * 4u);
     grab((void**)&ws.jump_dev, (size_t)2u * kJumpWords * 4u);
-    grab((void**)&ws.qcounts, (size_t)kMaxFilterWaves * 4u);
+    grab((void**)&ws.backup, ((size_t)8u * npix + 8u) * 4u);
     grab((void**)&ws.unit_cost, (size_t)args.n_units * 4u);
     grab((void**)&ws.unit_order, (size_t)args.n_units * 4u);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ws.unit_host, (size_t)2u * args.n_units * sizeof(uint32_t), hipHostMallocDefault);
@@ -2161,7 +2219,13 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
         grab((void**)&ws.draws, (size_t)2u * CRT_RAY_STACK * n_lp * 4u);
         grab((void**)&ws.coop_tabs, (size_t)kCoopTables * kJumpWords * 4u);
     }
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ws.ctrs_host, WF_CTR_COUNT * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess)
+        e = hipHostMalloc((void**)&ws.ctrs_host, (size_t)WF_CTR_RING * WF_CTR_COUNT * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) {
+        hipEvent_t* ev = new hipEvent_t[WF_CTR_RING]();
+        ws.round_events = ev;
+        for (uint32_t k = 0; k < WF_CTR_RING && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         wavefront_release(ws);
         return e;
@@ -2173,9 +2237,139 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     ws.n_lights = lights;
     ws.qcap = qcap;
     ws.max_shadow_rays = args.max_shadow_rays;
+    ws.npix = npix;
     ws.bytes = total;
     return hipSuccess;
 }
+
+namespace {
+
+// One round's kernels behind the trace kernel, sized without the host knowing the round's counts: fixed grids
+// that read the number of records and queued rays from the device counters.
+struct Grids {
+    uint32_t filter, resolve, shade;
+    uint32_t qusable; // queue entries left when every filter wave wastes a whole piece
+};
+
+// The trace kernel(s) of one round.  The first n_coop units of the launch order (the most expensive ones) go
+// through the cooperative kernel, the rest through the per-pixel one; when both run, the cooperative kernel
+// goes to a side stream so that the two share the GPU.  (Measured on the half-frame launch, trace time: this
+// way round, launched into an idle GPU after the pre-pass's host round trip, 5.2 ms; the kernels' streams
+// swapped, or the launch queued behind the previous frame without the round trip, 5.9 ms.)
+hipError_t launch_trace(const RenderArgs& args, WfWorkspace& ws, const WfArgs& w, uint32_t first, uint32_t n_coop,
+                        hipStream_t stream, EventTimer* timer) {
+    hipError_t e = hipSuccess;
+    EventTimer::Span* span = timer ? timer->begin(WF_K_TRACE, stream) : nullptr;
+    const dim3 tblock(64 * kTraceWaves);
+    const uint32_t rest = args.n_units - n_coop;
+    hipStream_t cstream = stream;
+    if (n_coop != 0u && rest != 0u) {
+        cstream = static_cast<hipStream_t>(ws.side_stream);
+        e = hipEventRecord(static_cast<hipEvent_t>(ws.fork_event), stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(cstream, static_cast<hipEvent_t>(ws.fork_event), 0);
+        if (e != hipSuccess) return e;
+    }
+    if (n_coop != 0u)
+        hipLaunchKernelGGL(wf_trace_kernel<true>, dim3((n_coop * kCoopSplit + kTraceWaves - 1u) / kTraceWaves), tblock, 0,
+                           cstream, w, first, 0u, n_coop);
+    if (rest != 0u)
+        hipLaunchKernelGGL(wf_trace_kernel<false>, dim3((rest + kTraceWaves - 1u) / kTraceWaves), tblock, 0, stream, w, first,
+                           n_coop, args.n_units);
+    if (cstream != stream) {
+        e = hipEventRecord(static_cast<hipEvent_t>(ws.join_event), cstream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, static_cast<hipEvent_t>(ws.join_event), 0);
+        if (e != hipSuccess) return e;
+    }
+    EventTimer::end(span, stream);
+    return hipSuccess;
+}
+
+// Renders the frame.  safe == false: rounds are queued back to back, every kernel takes its sizes from the
+// device counters, the host only looks (one round late) at whether pixels are still unfinished.  If more
+// shadow rays stay undecided than the queue holds, the device drops rays and raises WF_CTR_QOVERFLOW.
+// safe == true: the host waits for each round's record count and runs filter and resolve over batches of
+// records small enough for the queue to hold every ray of a batch.
+hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const Grids& g, uint32_t n_coop, bool safe,
+                     bool leave_running, hipStream_t stream, EventTimer* timer, uint32_t flags_out[2]) {
+    const bool coop = n_coop != 0u; // records may carry ordinals
+    hipEvent_t* ev = static_cast<hipEvent_t*>(ws.round_events);
+    hipError_t e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_COUNT * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    flags_out[0] = flags_out[1] = 0u;
+    const uint64_t rays_per_record = args.max_shadow_rays ? args.max_shadow_rays : 1u;
+    // Measuring aid (bench.py --workload c5): stop after this many rounds, leaving the frame unfinished, to time
+    // the steady state of a launch whose whole frame takes an hour.  Never set it when the image matters.
+    uint32_t max_rounds = 0xffffffffu;
+    if (const char* env = getenv("CRT_WF_MAX_ROUNDS")) max_rounds = (uint32_t)atoi(env) > 0 ? (uint32_t)atoi(env) : 1u;
+    uint32_t first = 1u;
+    for (uint32_t round = 0;; ++round) {
+        uint32_t* host = ws.ctrs_host + (size_t)(round % WF_CTR_RING) * WF_CTR_COUNT;
+        e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_ERROR * sizeof(uint32_t), stream); // the flags behind it are sticky
+        if (e != hipSuccess) return e;
+        // slot tags default to TAG_ADD (0): the trace kernel stores only the rare end-of-call / end-of-pixel marks
+        e = hipMemsetAsync(ws.tags, 0, (size_t)ws.quota * ws.n_lp, stream);
+        if (e != hipSuccess) return e;
+        e = launch_trace(args, ws, w, first, n_coop, stream, timer);
+        if (e != hipSuccess) return e;
+        if (!safe) {
+            if (coop) WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel<true>, dim3(g.filter), dim3(64), 0, stream, w, 0u, kFromCounter));
+            else WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel<false>, dim3(g.filter), dim3(64), 0, stream, w, 0u, kFromCounter));
+            if (args.audit) hipLaunchKernelGGL(wf_audit_kernel, dim3(g.filter), dim3(64), 0, stream, w, 0u, kFromCounter);
+            WF_TIMED(WF_K_RESOLVE, hipLaunchKernelGGL(wf_resolve_kernel, dim3(g.resolve), dim3(64), 0, stream, w));
+        } else {
+            e = hipMemcpyAsync(host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return e;
+            const uint32_t n_work = host[WF_CTR_WORK] < ws.cap_work ? host[WF_CTR_WORK] : ws.cap_work;
+            uint64_t batch = g.qusable / rays_per_record / 64u * 64u;
+            if (batch == 0) return hipErrorInvalidValue; // a single group's shadow rays exceed the queue
+            if (batch > 0x40000000ull) batch = 0x40000000ull;
+            for (uint32_t b0 = 0; b0 < n_work; b0 += (uint32_t)batch) {
+                const uint32_t b1 = n_work - b0 > batch ? b0 + (uint32_t)batch : n_work;
+                const uint32_t groups = (b1 - b0 + 63u) / 64u;
+                const uint32_t fgrid = groups < g.filter ? groups : g.filter;
+                e = hipMemsetAsync(ws.ctrs + WF_CTR_QUEUE, 0, sizeof(uint32_t), stream);
+                if (e != hipSuccess) return e;
+                if (coop) WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel<true>, dim3(fgrid), dim3(64), 0, stream, w, b0, b1));
+                else WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel<false>, dim3(fgrid), dim3(64), 0, stream, w, b0, b1));
+                if (args.audit) hipLaunchKernelGGL(wf_audit_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
+                WF_TIMED(WF_K_RESOLVE, hipLaunchKernelGGL(wf_resolve_kernel, dim3(g.resolve), dim3(64), 0, stream, w));
+            }
+        }
+        WF_TIMED(WF_K_SHADE, hipLaunchKernelGGL(wf_shade_kernel, dim3(g.shade), dim3(64), 0, stream, w));
+        if (args.n_units < 4096u) WF_TIMED(WF_K_SUM, hipLaunchKernelGGL(wf_sum_kernel<true>, dim3(args.n_units), dim3(64), 0, stream, w, first));
+        else WF_TIMED(WF_K_SUM, hipLaunchKernelGGL(wf_sum_kernel<false>, dim3(args.n_units), dim3(64), 0, stream, w, first));
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        first = 0u;
+        if (leave_running) return hipSuccess; // one round, nothing that can overflow: nothing to wait for
+        if (round + 1u >= max_rounds) break;
+        if (safe) {
+            if (host[WF_CTR_ACTIVE] == 0u) break;
+            continue;
+        }
+        // this round's counters, flags included, to the host; the host reads them one round late
+        e = hipMemcpyAsync(host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipEventRecord(ev[round % WF_CTR_RING], stream);
+        if (e != hipSuccess) return e;
+        if (ws.single_round) break;
+        if (round >= 1u) {
+            const uint32_t* prev = ws.ctrs_host + (size_t)((round - 1u) % WF_CTR_RING) * WF_CTR_COUNT;
+            e = hipEventSynchronize(ev[(round - 1u) % WF_CTR_RING]);
+            if (e != hipSuccess) return e;
+            // nothing was left after the round before: the round just queued finds no work
+            if (prev[WF_CTR_ACTIVE] == 0u || prev[WF_CTR_ERROR] != 0u || prev[WF_CTR_QOVERFLOW] != 0u) break;
+        }
+    }
+    e = hipMemcpyAsync(ws.ctrs_host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    flags_out[0] = ws.ctrs_host[WF_CTR_ERROR];
+    flags_out[1] = ws.ctrs_host[WF_CTR_QOVERFLOW];
+    return hipSuccess;
+}
+
+} // namespace
 
 hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow) {
     *overflow = false;
@@ -2193,6 +2387,7 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         g_resident_cus[dev] = cus > 0 ? cus : 1;
     }
     const uint32_t cus = (uint32_t)g_resident_cus[dev];
+    if (ws.npix != args.nx * args.ny) return hipErrorInvalidValue; // wavefront_reserve was given another image
 
     WfArgs w;
     w.r = args;
@@ -2214,11 +2409,10 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     w.jump_tabs = ws.jump_dev;
     w.jump_n[0] = ws.jump_n[0];
     w.jump_n[1] = ws.jump_n[1];
-    w.qcounts = ws.qcounts;
-    w.region_cap = 0;
     w.draws = ws.draws;
     w.coop_tabs = ws.coop_tabs;
     w.unit_order = nullptr;
+    ws.single_round = args.aa_iter <= 1u && slots_per_pixel(args) <= ws.quota;
     const bool coop = args.cooperative != 0u && args.gl_iter != 0u;
     if (coop && (!ws.draws || !ws.coop_tabs)) return hipErrorInvalidValue; // wavefront_reserve was given other arguments
     uint32_t n_coop = 0; // units for the cooperative kernel: that share of the launch, at least one unit
@@ -2238,18 +2432,29 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         }
     }
 
-    // shadow rays per shade record, for sizing the filter batches
-    // Filter launches: G persistent waves, each takes every G-th group of 64 records and owns a queue
-    // region large enough for all shadow rays of its groups.
-    const uint64_t rays_per_group = 64ull * (args.max_shadow_rays ? args.max_shadow_rays : 1u);
-    uint32_t fwaves = cus * 4u * CRT_WF_FILTER_WAVES;
-    if (fwaves > kMaxFilterWaves) fwaves = kMaxFilterWaves;
-    if ((uint64_t)fwaves * rays_per_group > ws.qcap) fwaves = (uint32_t)(ws.qcap / rays_per_group);
-    if (fwaves == 0) return hipErrorInvalidValue; // a single group's shadow rays exceed the queue
-    const uint32_t groups_per_wave = (uint32_t)(ws.qcap / ((uint64_t)fwaves * rays_per_group));
-    const uint64_t batch64 = (uint64_t)groups_per_wave * fwaves * 64u;
-    const uint32_t batch = batch64 > 0x40000000ull ? 0x40000000u : (uint32_t)batch64;
-    w.region_cap = (uint32_t)(groups_per_wave * rays_per_group);
+    // Grids that do not depend on the round's counts, only on what the workspace can hold.
+    Grids g;
+    {
+        const uint32_t groups = (ws.cap_work + 63u) / 64u;
+        g.filter = cus * 4u * CRT_WF_FILTER_WAVES;
+        if (g.filter > kMaxFilterWaves) g.filter = kMaxFilterWaves;
+        if (g.filter > groups) g.filter = groups;
+        // resolve: grid-stride over the queue; about one block per 32 groups of rays if a twentieth of the
+        // shadow rays stay undecided (a block's set-up costs about as much as two groups)
+        const uint64_t rays = (uint64_t)ws.cap_work * (args.max_shadow_rays ? args.max_shadow_rays : 1u);
+        uint64_t rgrid = rays / (64u * 32u * 20u);
+        if (rgrid < cus * 16u) rgrid = cus * 16u;
+        if (rgrid > 131072u) rgrid = 131072u;
+        if (rgrid > (ws.qcap + 63u) / 64u) rgrid = (ws.qcap + 63u) / 64u;
+        g.resolve = (uint32_t)rgrid;
+        g.shade = groups;
+        // the filter waves reserve the queue in pieces: large enough to keep the atomics rare, small enough
+        // that the waves' unused remainders stay below a quarter of the queue
+        uint32_t qchunk = ws.qcap / (4u * g.filter) / 64u * 64u;
+        w.qchunk = qchunk < 64u ? 64u : (qchunk > 2048u ? 2048u : qchunk);
+        const uint64_t waste = (uint64_t)g.filter * w.qchunk;
+        g.qusable = waste < ws.qcap ? (uint32_t)(ws.qcap - waste) : 0u;
+    }
 
     // generator jump tables for this scene and these settings
     {
@@ -2268,26 +2473,10 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         w.jump_n[1] = ws.jump_n[1];
         if (coop && ws.coop_n != want[0]) {
             std::vector<uint32_t> tabs((size_t)kCoopTables * kJumpWords, 0u);
-            // table k-1 = k times the jump of one shaded point: every entry of the previous table, itself a
-            // generator state, is put through the one-point table once more
+            // table k-1 = k times the jump of one shaded point
             build_jump_table(want[0], tabs.data());
-            for (uint32_t t = 1; t < kCoopTables; ++t) {
-                const uint32_t* prev = tabs.data() + (size_t)(t - 1u) * kJumpWords;
-                uint32_t* next = tabs.data() + (size_t)t * kJumpWords;
-                for (uint32_t en = 0; en < kJumpEntries; ++en) {
-                    const uint32_t in[5] = {prev[4u * en], prev[4u * en + 1u], prev[4u * en + 2u], prev[4u * en + 3u],
-                                            prev[4u * kJumpEntries + en]};
-                    uint32_t out[5] = {0, 0, 0, 0, 0};
-                    for (uint32_t wd = 0; wd < 5u; ++wd)
-                        for (uint32_t nb = 0; nb < 8u; ++nb) {
-                            const uint32_t idx = (wd * 8u + nb) * 16u + ((in[wd] >> (4u * nb)) & 15u);
-                            for (uint32_t o = 0; o < 4u; ++o) out[o] ^= tabs[4u * idx + o];
-                            out[4] ^= tabs[4u * kJumpEntries + idx];
-                        }
-                    for (uint32_t o = 0; o < 4u; ++o) next[4u * en + o] = out[o];
-                    next[4u * kJumpEntries + en] = out[4];
-                }
-            }
+            for (uint32_t t = 1; t < kCoopTables; ++t)
+                compose_jump_tables(tabs.data() + (size_t)(t - 1u) * kJumpWords, tabs.data(), tabs.data() + (size_t)t * kJumpWords);
             e = hipMemcpyAsync(ws.coop_tabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
             if (e != hipSuccess) return e;
@@ -2318,101 +2507,38 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         ws.order_key = args;
         ws.order_valid = true;
     }
-    uint32_t first = 1u;
-    e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_COUNT * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    for (;;) {
-        e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_ERROR * sizeof(uint32_t), stream); // the error word is sticky
+
+    // Can the queue overflow at all?  Not when it holds every shadow ray of a round's records.
+    const uint64_t rays_per_record = args.max_shadow_rays ? args.max_shadow_rays : 1u;
+    const bool can_overflow = (uint64_t)ws.cap_work * rays_per_record > ws.qcap;
+    const size_t npix = ws.npix;
+    if (can_overflow) {
+        // what a second rendering of this frame starts from: generator states, work counters, tallies
+        e = hipMemcpyAsync(ws.backup, args.rng, npix * 6u * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(ws.backup + 6u * npix, args.counters, npix * 2u * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(ws.backup + 8u * npix, args.wave_tallies, 8u * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
         if (e != hipSuccess) return e;
-        // slot tags default to TAG_ADD (0): the trace kernel stores only the rare end-of-call / end-of-pixel marks
-        e = hipMemsetAsync(ws.tags, 0, (size_t)ws.quota * ws.n_lp, stream);
-        if (e != hipSuccess) return e;
-        {
-            // The first n_coop units of the launch order (the most expensive ones) go through the cooperative
-            // kernel, the rest through the per-pixel one; when both run, the cooperative kernel goes to a side
-            // stream so that the two share the GPU.  (Measured on the half-frame launch, trace time: this way
-            // round, launched into an idle GPU after the pre-pass's host round trip, 5.2 ms; the kernels' streams
-            // swapped, or the launch queued behind the previous frame without the round trip, 5.9 ms.)
-            EventTimer::Span* span = timer ? timer->begin(WF_K_TRACE, stream) : nullptr;
-            const dim3 tblock(64 * kTraceWaves);
-            const uint32_t rest = args.n_units - n_coop;
-            hipStream_t cstream = stream;
-            if (n_coop != 0u && rest != 0u) {
-                cstream = static_cast<hipStream_t>(ws.side_stream);
-                e = hipEventRecord(static_cast<hipEvent_t>(ws.fork_event), stream);
-                if (e == hipSuccess) e = hipStreamWaitEvent(cstream, static_cast<hipEvent_t>(ws.fork_event), 0);
-                if (e != hipSuccess) return e;
-            }
-            if (n_coop != 0u)
-                hipLaunchKernelGGL(wf_trace_kernel<true>, dim3((n_coop * kCoopSplit + kTraceWaves - 1u) / kTraceWaves), tblock, 0,
-                                   cstream, w, first, 0u, n_coop);
-            if (rest != 0u)
-                hipLaunchKernelGGL(wf_trace_kernel<false>, dim3((rest + kTraceWaves - 1u) / kTraceWaves), tblock, 0, stream, w, first,
-                                   n_coop, args.n_units);
-            if (cstream != stream) {
-                e = hipEventRecord(static_cast<hipEvent_t>(ws.join_event), cstream);
-                if (e == hipSuccess) e = hipStreamWaitEvent(stream, static_cast<hipEvent_t>(ws.join_event), 0);
-                if (e != hipSuccess) return e;
-            }
-            EventTimer::end(span, stream);
-        }
-        e = hipMemcpyAsync(ws.ctrs_host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (e != hipSuccess) return e;
-        e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) return e;
-        const uint32_t n_work = ws.ctrs_host[WF_CTR_WORK];
-        const uint32_t n_active = ws.ctrs_host[WF_CTR_ACTIVE];
-        if (ws.ctrs_host[WF_CTR_ERROR] != 0u || n_work > ws.cap_work) {
-            *overflow = true;
-            return hipSuccess;
-        }
-        // Filter and resolve.  A queue region sized for the worst case (every shadow ray undecided) allows
-        // `batch` records per launch; since normally a few per cent are undecided, the first attempt gives
-        // every wave kOptimism times as many records.  If a region overflows, the kernels have dropped rays
-        // (never written out of bounds) and the round's visibility is redone with worst-case launches: the
-        // filter kernel rewrites every record's count from scratch.
-        for (uint32_t attempt = 0; attempt < 2u && n_work != 0u; ++attempt) {
-            const uint64_t step64 = attempt == 0u ? (uint64_t)batch * kOptimism : batch;
-            const uint32_t step = step64 > 0x40000000ull ? 0x40000000u : (uint32_t)step64;
-            for (uint32_t b0 = 0; b0 < n_work; b0 += step) {
-                const uint32_t b1 = n_work - b0 > step ? b0 + step : n_work;
-                const uint32_t groups = (b1 - b0 + 63u) / 64u;
-                const uint32_t fgrid = groups < fwaves ? groups : fwaves;
-                if (coop) WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel<true>, dim3(fgrid), dim3(64), 0, stream, w, b0, b1));
-                else WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel<false>, dim3(fgrid), dim3(64), 0, stream, w, b0, b1));
-                if (args.audit && attempt == 1u) hipLaunchKernelGGL(wf_audit_kernel, dim3(fgrid), dim3(64), 0, stream, w, b0, b1);
-                WF_TIMED(WF_K_RESOLVE,
-                         hipLaunchKernelGGL(wf_resolve_kernel, dim3(fgrid * kResolveSplit), dim3(64), 0, stream, w));
-            }
-            if (attempt == 1u) break;
-            e = hipMemcpyAsync(ws.ctrs_host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            if (e != hipSuccess) return e;
-            if (ws.ctrs_host[WF_CTR_QOVERFLOW] == 0u) {
-                if (args.audit) { // the audit reads records only, so it can follow the successful attempt
-                    const uint32_t groups = (n_work + 63u) / 64u;
-                    hipLaunchKernelGGL(wf_audit_kernel, dim3(groups < fwaves ? groups : fwaves), dim3(64), 0, stream, w, 0u, n_work);
-                }
-                break;
-            }
-            e = hipMemsetAsync(ws.ctrs + WF_CTR_QOVERFLOW, 0, sizeof(uint32_t), stream);
-            if (e != hipSuccess) return e;
-        }
-        if (n_work != 0u)
-            WF_TIMED(WF_K_SHADE, hipLaunchKernelGGL(wf_shade_kernel, dim3((n_work + 63u) / 64u), dim3(64), 0, stream, w, 0u, n_work));
-        if (args.n_units < 4096u) WF_TIMED(WF_K_SUM, hipLaunchKernelGGL(wf_sum_kernel<true>, dim3(args.n_units), dim3(64), 0, stream, w, first));
-        else WF_TIMED(WF_K_SUM, hipLaunchKernelGGL(wf_sum_kernel<false>, dim3(args.n_units), dim3(64), 0, stream, w, first));
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        first = 0u;
-        if (n_active == 0u) break;
     }
-    // the error word of the last filter batches
-    e = hipMemcpyAsync(ws.ctrs_host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    const bool leave_running = ws.single_round && !can_overflow && !timer && !args.audit;
+    uint32_t flags[2] = {0u, 0u};
+    e = run_frame(args, ws, w, g, n_coop, false, leave_running, stream, timer, flags);
     if (e != hipSuccess) return e;
-    e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return e;
-    if (ws.ctrs_host[WF_CTR_ERROR] != 0u) *overflow = true;
+    if (flags[0] == 0u && flags[1] != 0u && can_overflow) {
+        // rays were dropped: the same frame again from where it started, with launches that cannot overflow
+        e = hipMemcpyAsync(args.rng, ws.backup, npix * 6u * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(args.counters, ws.backup + 6u * npix, npix * 2u * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(args.wave_tallies, ws.backup + 8u * npix, 8u * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+        if (timer) timer->collect(ws);
+        ws.frames_redone += 1;
+        e = run_frame(args, ws, w, g, n_coop, true, false, stream, timer, flags);
+        if (e != hipSuccess) return e;
+    }
+    if (flags[0] != 0u || flags[1] != 0u) *overflow = true;
     if (timer) timer->collect(ws);
     return hipSuccess;
 }

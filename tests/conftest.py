@@ -2,6 +2,7 @@ import sys
 from pathlib import Path
 
 import pytest
+import torch  # noqa: F401  (first, so that the process ends up with one HIP runtime whichever test file runs alone)
 
 ROOT = Path(__file__).resolve().parent.parent
 for p in (str(ROOT), str(ROOT / "tests")):

@@ -8,6 +8,7 @@ cp gpurun_out/${TAG}_kt/kt_kernel_stats.csv gpurun_out/${TAG}_kernel_stats.csv
 grep '"metric"' gpurun_out/${TAG}_kt.log > gpurun_out/${TAG}_bench_under_rocprof.json
 bash tools/prof_pmc.sh ${TAG} > gpurun_out/${TAG}_pmc_summary.txt 2>&1 || exit 1
 bash tools/prof_pmc3.sh ${TAG} >> gpurun_out/${TAG}_pmc_summary.txt 2>&1 || exit 1
+bash tools/prof_pmc4.sh ${TAG} >> gpurun_out/${TAG}_pmc_summary.txt 2>&1 || exit 1
 bash tools/prof_traffic.sh ${TAG} > gpurun_out/${TAG}_traffic.txt 2>&1 || exit 1
 cat gpurun_out/${TAG}_traffic.txt
 cat gpurun_out/${TAG}_kernel_stats.csv
