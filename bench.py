@@ -120,11 +120,13 @@ def config5(args, torch, crt):
             compact = torch.empty(n, dtype=torch.float32, device=dev)
             ctx.reserve_workspace(st, 0, 8)
             torch.cuda.synchronize(dev)
+            print(f"# sample: rank 0 of 8, {args.c5_rounds} rounds ...", file=sys.stderr, flush=True)
             t0 = time.perf_counter()
             ctx.render_shard(st, 0, 8, compact.data_ptr(), stream.cuda_stream)  # unfinished on purpose
             torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t0
             done = int(ctx.stats(st).shade_points)
+            print(f"# sample: {done} shaded points in {dt:.2f} s", file=sys.stderr, flush=True)
     finally:
         del os.environ["CRT_WF_MAX_ROUNDS"]
     rate = done / dt

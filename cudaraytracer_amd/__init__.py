@@ -74,7 +74,10 @@ def lib():
             "crt_to_rgba8": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
             "crt_write_ppm": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
         }
+        variant = "CRT_HIP_LIB" in __import__("os").environ  # an older build measured for comparison may lack entry points
         for name, (res, args) in sig.items():
+            if variant and not hasattr(L, name):
+                continue
             fn = getattr(L, name)  # AttributeError here = the library does not export the declared ABI
             fn.restype = res
             fn.argtypes = args

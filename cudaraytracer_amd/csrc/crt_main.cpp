@@ -5,7 +5,10 @@
 //
 //   crt_main [--nx N] [--ny N] [--aa_iter N] [--ref_iter N] [--gl_iter N] [--ind_rays N]
 //            [--shadowSamples N] [--tx N] [--ty N] [--blocksPerDraw N] [--progressive]
-//            [--seed S] [--device D] [--out file.hdr] [--preview file.ppm]
+//            [--seed S] [--device D] [--gpus N] [--out file.hdr] [--preview file.ppm]
+//
+// --gpus N renders on devices 0..N-1 of the node: interleaved 8x8 tiles, one RCCL gather to device 0
+// (craytracer/multi_gpu.hpp); the image is the same, bit for bit, as on one GPU.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +17,7 @@
 #include <string>
 
 #include "../include/craytracer/craytracer.hpp"
+#include "../include/craytracer/multi_gpu.hpp"
 
 using namespace craytracer;
 
@@ -27,6 +31,7 @@ int main(int argc, char** argv) {
     RenderSettings s;
     unsigned long long seed = static_cast<unsigned long long>(std::time(nullptr)); // main.cu:952
     int device = 0;
+    int gpus = 0; // 0: the single-GPU path on `device`
     std::string out = "file.hdr";
     std::string preview; // 8-bit view of the frame, what the reference shows in its window (main.cu:812-818)
     for (int i = 1; i < argc; ++i) {
@@ -51,6 +56,7 @@ int main(int argc, char** argv) {
         else if (a == "--progressive") s.renderAllAtOnce = false;
         else if (a == "--seed") seed = std::strtoull(next(), nullptr, 10);
         else if (a == "--device") device = std::atoi(next());
+        else if (a == "--gpus") gpus = std::atoi(next());
         else if (a == "--out") out = next();
         else if (a == "--preview") preview = next();
         else {
@@ -61,17 +67,29 @@ int main(int argc, char** argv) {
     try {
         using clock = std::chrono::steady_clock;
         auto t0 = clock::now();
-        Renderer renderer(device);
-        std::printf("HIP initialized.\n");
         CornellBox box(s.shadowSamples);
-        renderer.randomInit(s.nx, s.ny, seed);
-        renderer.setScene(box.camera, box.world, box.lights);
-        auto t1 = clock::now();
-        printTime("Create World", std::chrono::duration<double, std::milli>(t1 - t0).count());
-
-        std::vector<float> fb = renderer.render(s); // returns after the device finished
-        auto t2 = clock::now();
-        printTime("Render", std::chrono::duration<double, std::milli>(t2 - t1).count());
+        std::vector<float> fb;
+        if (gpus > 0) {
+            std::vector<int> devices;
+            for (int d = 0; d < gpus; ++d) devices.push_back(d);
+            MultiGpuRenderer renderer(devices);
+            std::printf("HIP initialized on %d GPU%s.\n", gpus, gpus == 1 ? "" : "s");
+            renderer.randomInit(s.nx, s.ny, seed);
+            renderer.setScene(box.camera, box.world, box.lights);
+            auto t1 = clock::now();
+            printTime("Create World", std::chrono::duration<double, std::milli>(t1 - t0).count());
+            fb = renderer.render(s);
+            printTime("Render", std::chrono::duration<double, std::milli>(clock::now() - t1).count());
+        } else {
+            Renderer renderer(device);
+            std::printf("HIP initialized.\n");
+            renderer.randomInit(s.nx, s.ny, seed);
+            renderer.setScene(box.camera, box.world, box.lights);
+            auto t1 = clock::now();
+            printTime("Create World", std::chrono::duration<double, std::milli>(t1 - t0).count());
+            fb = renderer.render(s); // returns after the device finished
+            printTime("Render", std::chrono::duration<double, std::milli>(clock::now() - t1).count());
+        }
 
         std::printf("Saving image...");
         if (crt_write_hdr(out.c_str(), static_cast<int>(s.nx), static_cast<int>(s.ny), 4, fb.data()) != CRT_OK) {

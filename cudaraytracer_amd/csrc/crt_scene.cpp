@@ -4,6 +4,7 @@
 #include "crt_scene.hpp"
 
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <string.h>
 
@@ -217,6 +218,41 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
             st(d.nor, q.nor);
             fill_uv(d.uv, q);
         }
+    }
+
+    // Where a light can only ever add the ambient term (DevLight::dark_lo/hi).
+    {
+        auto finite3 = [](const float* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); };
+        bool possible = true;
+        for (uint32_t l = 0; l < in->n_lights; ++l) {
+            DevLight& d = out->lights[l];
+            d.dark_lo = d.dark_hi = 0u;
+            if (d.kind != CRT_LIGHT_AREA) {
+                possible = false;
+                continue;
+            }
+            if (!d.initialized) continue; // adds the ambient product wherever the point is (AreaLight.hpp:586)
+            if (d.two_sided || d.shadow_samples == 0u || !std::isfinite(d.intensity) || !finite3(d.color)) {
+                possible = false;
+                continue;
+            }
+            uint64_t mask = 0;
+            for (uint32_t g = 0; g < in->n_geometry; ++g) {
+                const DevGeomShade& m = out->shade[g];
+                bool ok = finite3(m.diffuse) && finite3(m.specular);
+                for (int k = 0; k < 3 && ok; ++k) {
+                    const float amb = m.ambient[k] * d.color[k];
+                    uint32_t bits;
+                    memcpy(&bits, &amb, 4);
+                    ok = bits <= 0x7f800000u; // +0 .. +inf: adding a zero of either sign changes no bit
+                }
+                if (ok) mask |= 1ull << g;
+            }
+            d.dark_lo = (uint32_t)mask;
+            d.dark_hi = (uint32_t)(mask >> 32);
+            if (mask == 0) possible = false;
+        }
+        out->dark_possible = possible ? 1u : 0u;
     }
 
     // Per (light, quad) culling constants.  Along a shadow ray from P (+0.01 along the ray) to a light

@@ -97,6 +97,13 @@ struct alignas(64) DevLight {
     // _hittedLight (AreaLight.hpp:382-432), same derivation as a quad
     float nor[3];
     DevGeomUV uv;
+    // Primitives (bit g of dark_hi:dark_lo) on which this light leaves nothing but the material's ambient term
+    // wherever the shaded point is not "behind" it: a one-sided area light whose LTC sums are then set to zero
+    // (AreaLight.hpp:292-296), with every factor of the zeroed terms finite and the ambient product free of
+    // negative zeros and NaNs, so that ambient + ((0 + 0) * intensity) * visibility is the ambient product bit
+    // for bit.  Zero for every other light.
+    uint32_t dark_lo, dark_hi;
+    uint32_t pad1[14];
 };
 
 struct alignas(64) DevCamera {
@@ -111,7 +118,8 @@ struct alignas(64) DevScene {
     DevCamera cam;
     uint32_t n_geom;
     uint32_t n_lights;
-    uint32_t pad[14];
+    uint32_t dark_possible; // 1: every light is an area light that is uninitialised or has a non-empty dark set
+    uint32_t pad[13];
     DevGeomHot hot[CRT_MAX_GEOMETRY];
     DevGeomUV uv[CRT_MAX_GEOMETRY];
     DevGeomShade shade[CRT_MAX_GEOMETRY];

@@ -851,7 +851,7 @@ DI void child_ray(V3 hp, V3 hn, V4 patt, V4 pdiff, float r1, float r2, float inv
 // What the tree walk reads of a primitive by per-lane index, copied to LDS once per workgroup: a lone
 // wave spends most of a step waiting, and an LDS read returns in a quarter of the time of a cached
 // global one.  Row layout: vertex normals [0..11], Material::diffuse [12..15], refractIndex [16],
-// kind [17], sphere centre [18..20].
+// kind [17], sphere centre [18..20], Material::ambient rgb [21..23].
 constexpr uint32_t kPrimWords = 24;
 typedef float PrimTable[CRT_MAX_GEOMETRY][kPrimWords];
 DI void fill_prim_table(ScenePtr sc, PrimTable& t, uint32_t tid, uint32_t nthreads) {
@@ -864,6 +864,7 @@ DI void fill_prim_table(ScenePtr sc, PrimTable& t, uint32_t tid, uint32_t nthrea
         else if (wd == 16u) v = sc->shade[i].refract_index;
         else if (wd == 17u) v = u2f(sc->hot[i].kind);
         else if (wd < 21u) v = sc->hot[i].o[wd - 18u];
+        else v = sc->shade[i].ambient[wd - 21u];
         t[i][wd] = v;
     }
 }
@@ -912,6 +913,38 @@ DI uint32_t pop_ray(ScenePtr sc, const PrimTable& prim, V3& cur_o, V3& cur_d, V4
     cur_att = cur_att * V4{pr[12], pr[13], pr[14], pr[15]};
     cur_ref = cur_ref - 1u;
     return POP_BOUNCE;
+}
+
+// A diffuse hit that no light can do more for than add the material's ambient term needs neither shadow
+// rays nor the LTC integrals: LightList::calculateColor (LightList.hpp:23-36) then sums, per light,
+// vec4(ambient * light colour, 1) -- an uninitialised area light returns just that (AreaLight.hpp:586-589), and
+// a one-sided area light that the point is not "behind" has both polygon sums set to zero
+// (AreaLight.hpp:249-251,292-296), which leaves ambient + ((0 + 0) * intensity) * visibility = ambient for the
+// lights and materials DevLight::dark_lo/hi admits.  In the Cornell box that is every hit on the ceiling.  The
+// hit still counts as a shaded point and still moves the generator past its light samples; it just writes
+// attenuation x that sum into its result slot now instead of becoming a record.  Returns false when some
+// light needs the full evaluation.
+DI bool ambient_only(ScenePtr sc, const PrimTable& prim, V3 P, uint32_t geom, V4 att, float4& out) {
+    if (sc->dark_possible == 0u) return false;
+    const float* pr = prim[geom];
+    const V3 mat_ambient = mk3(pr[21], pr[22], pr[23]);
+    V4 direct = V4{0, 0, 0, 0};
+    bool all = true;
+    const uint32_t n_lights = sc->n_lights;
+    for (uint32_t li = 0; li < n_lights; ++li) {
+        const DevLight CRT_CONST* L = &sc->lights[li];
+        if (L->initialized) {
+            const V3 w0 = ld3c(L->pts[0]) - P;
+            const bool behind = dot3(w0, ld3c(L->light_normal)) < 0.0f;
+            const uint32_t word = geom < 32u ? L->dark_lo : L->dark_hi;
+            if (behind || ((word >> (geom & 31u)) & 1u) == 0u) all = false;
+        }
+        const V3 amb = mat_ambient * ld3c(L->color);
+        direct = direct + V4{amb.x, amb.y, amb.z, 1.0f};
+    }
+    const V4 c = att * direct; // final_color += attenuation * light (main.cu:195)
+    out = make_float4(c.x, c.y, c.z, c.w);
+    return all;
 }
 
 // Stores one shade record.
@@ -1073,7 +1106,7 @@ __global__ void __launch_bounds__(64) wf_cost_kernel(WfArgs w, uint32_t* unit_co
 }
 
 template <bool COOP>
-__global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kernel(WfArgs w, uint32_t first, uint32_t slot_begin,
+__global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w, uint32_t first, uint32_t slot_begin,
                                                                                    uint32_t slot_end) {
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
@@ -1342,9 +1375,14 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
         // ---- record the diffuse hits of this step (all lanes are here together)
         const uint64_t em = __ballot(emit);
         if (em != 0) {
-            const uint32_t my_wi = reserve_records(w, wc, em, lane);
+            float4 dark_c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const bool dark = emit && ambient_only(sc, s_prim, n_P, n_geom, n_att, dark_c);
+            const uint64_t rm = __ballot(emit && !dark);
+            uint32_t my_wi = 0;
+            if (rm != 0) my_wi = reserve_records(w, wc, rm, lane);
             if (emit) {
-                store_record(w, my_wi, n_P, n_N, n_view, n_att, n_geom, rng, (uint32_t)((size_t)cnt * n_lp + lp));
+                if (dark) w.contrib[(size_t)cnt * n_lp + lp] = dark_c;
+                else store_record(w, my_wi, n_P, n_N, n_view, n_att, n_geom, rng, (uint32_t)((size_t)cnt * n_lp + lp));
                 ++cnt;
                 ++cnt_shade;
                 // the light samples of this hit (drawn by the filter kernel from the recorded state)
@@ -1452,9 +1490,13 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                     }
                 }
                 PROF_MARK(5);
+                // m_rec: the batch's diffuse hits in child order (each moves the generator by one shaded point)
                 const uint64_t m_slot = __ballot(outcome != 0u), m_rec = __ballot(outcome == 2u);
                 const uint32_t n_rec = (uint32_t)__popcll(m_rec);
                 const uint32_t slot_k = o_cnt + lane_rank(m_slot);
+                float4 dark_c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const bool dark = outcome == 2u && ambient_only(sc, s_prim, c_P, c_geom, r_att, dark_c);
+                const uint64_t m_store = __ballot(outcome == 2u && !dark); // those that become records
                 // the k-th diffuse hit's record keeps the owner's generator state and k; the owner continues
                 // n_rec shaded points further on
                 Rng nr = o_rng;
@@ -1464,9 +1506,10 @@ __global__ void __launch_bounds__(64 * kTraceWaves, COOP ? 2 : 4) wf_trace_kerne
                     const V4 c = r_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
                     w.contrib[(size_t)slot_k * n_lp + o_lp] = make_float4(c.x, c.y, c.z, c.w);
                 }
-                if (m_rec != 0) {
-                    const uint32_t my_wi = reserve_records(w, wc, m_rec, lane);
-                    if (outcome == 2u)
+                if (dark) w.contrib[(size_t)slot_k * n_lp + o_lp] = dark_c;
+                if (m_store != 0) {
+                    const uint32_t my_wi = reserve_records(w, wc, m_store, lane);
+                    if (outcome == 2u && !dark)
                         store_record(w, my_wi, c_P, c_N, c_view, r_att, c_geom, o_rng, (uint32_t)((size_t)slot_k * n_lp + o_lp),
                                      lane_rank(m_rec));
                 }

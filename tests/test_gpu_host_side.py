@@ -50,6 +50,20 @@ def test_crt_main_writes_the_file_the_abi_path_would(tmp_path, oracle, progressi
     assert np.array_equal(np.frombuffer(raw[len(head):], np.uint8).reshape(48, 64, 3), crt.to_rgba8(fb)[..., :3])
 
 
+def test_crt_main_multi_gpu_host_path_gives_the_single_gpu_file(tmp_path):
+    """--gpus N goes through craytracer::MultiGpuRenderer: one context and one shard per device, an RCCL gather
+    to device 0, crt_scatter_shards.  One GPU is what this box has, so N = 1 here (a communicator of one rank,
+    the gather to itself); the split itself is covered on one GPU by the shard tests of test_gpu_parity.py."""
+    a, b = tmp_path / "one.hdr", tmp_path / "multi.hdr"
+    common = ["--nx", 72, "--ny", 40, "--gl_iter", 1, "--ind_rays", 6, "--shadowSamples", 7, "--seed", 9]
+    r1 = _run_main(*common, "--out", a)
+    r2 = _run_main(*common, "--gpus", 1, "--out", b)
+    assert r1.returncode == 0, r1.stderr
+    assert r2.returncode == 0, r2.stderr
+    assert "1 GPU" in r2.stdout
+    assert a.read_bytes() == b.read_bytes()
+
+
 @pytest.mark.parametrize("bad", [("--tx", 0), ("--ty", 0), ("--blocksPerDraw", 0)])
 def test_crt_main_reports_a_bad_block_shape_instead_of_dying(tmp_path, bad):
     """The reference's error convention is exit code 99 with a message (main.cu:896-903); a zero block shape in
