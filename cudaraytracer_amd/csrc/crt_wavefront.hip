@@ -2231,7 +2231,8 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     const uint32_t cap_work = ((quota * n_lp + trace_waves * kWorkChunk + kWorkChunk - 1u) / kWorkChunk) * kWorkChunk;
     // the queue of undecided shadow rays: room for every ray of a round if that is less than 2^30 rays
     // (12.9 GB); normally a few per cent of the rays get there
-    uint64_t qwant = (uint64_t)cap_work * (args.max_shadow_rays ? args.max_shadow_rays : 1u);
+    uint64_t qwant = (uint64_t)cap_work * (args.max_shadow_rays ? args.max_shadow_rays : 1u) +
+                     (uint64_t)kMaxFilterWaves * 2048u; // + the piece every filter wave may leave partly unused
     if (qwant > (1ull << 30)) qwant = 1ull << 30;
     if (qwant > budget_bytes / 36u) qwant = budget_bytes / 36u; // at most a third of the budget (12 B per ray)
     if (qwant < (1ull << 20)) qwant = 1ull << 20;
@@ -2350,7 +2351,7 @@ hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const G
         e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_ERROR * sizeof(uint32_t), stream); // the flags behind it are sticky
         if (e != hipSuccess) return e;
         // slot tags default to TAG_ADD (0): the trace kernel stores only the rare end-of-call / end-of-pixel marks
-        e = hipMemsetAsync(ws.tags, 0, (size_t)ws.quota * ws.n_lp, stream);
+        e = hipMemsetAsync(ws.tags, 0, (size_t)w.quota * ws.n_lp, stream);
         if (e != hipSuccess) return e;
         e = launch_trace(args, ws, w, first, n_coop, stream, timer);
         if (e != hipSuccess) return e;
@@ -2435,8 +2436,17 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     WfArgs w;
     w.r = args;
     w.n_lp = ws.n_lp;
-    w.quota = ws.quota;
-    w.cap_work = ws.cap_work;
+    // What this launch can use of the workspace: a smaller tree than the workspace was sized for (the same
+    // context rendering gl_iter 0 after gl_iter 1) fills fewer slots per pixel, and the grids and the per-round
+    // clearing follow that, not the allocation.
+    {
+        const uint64_t slots = slots_per_pixel(args);
+        w.quota = slots < ws.quota ? (uint32_t)slots : ws.quota;
+    }
+    w.cap_work = ws.cap_work; // the planes' stride stays the allocation's
+    const uint32_t launch_waves = args.cooperative ? args.n_units * kCoopSplit : args.n_units;
+    const uint64_t used64 = (uint64_t)w.quota * ws.n_lp + (uint64_t)launch_waves * kWorkChunk;
+    const uint32_t cap_used = used64 < ws.cap_work ? (uint32_t)used64 : ws.cap_work; // record indices this launch can reach
     w.qcap = ws.qcap;
     w.ctrs = ws.ctrs;
     w.state = ws.state;
@@ -2478,13 +2488,13 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     // Grids that do not depend on the round's counts, only on what the workspace can hold.
     Grids g;
     {
-        const uint32_t groups = (ws.cap_work + 63u) / 64u;
+        const uint32_t groups = (cap_used + 63u) / 64u;
         g.filter = cus * 4u * CRT_WF_FILTER_WAVES;
         if (g.filter > kMaxFilterWaves) g.filter = kMaxFilterWaves;
         if (g.filter > groups) g.filter = groups;
         // resolve: grid-stride over the queue; about one block per 32 groups of rays if a twentieth of the
         // shadow rays stay undecided (a block's set-up costs about as much as two groups)
-        const uint64_t rays = (uint64_t)ws.cap_work * (args.max_shadow_rays ? args.max_shadow_rays : 1u);
+        const uint64_t rays = (uint64_t)cap_used * (args.max_shadow_rays ? args.max_shadow_rays : 1u);
         uint64_t rgrid = rays / (64u * 32u * 20u);
         if (rgrid < cus * 16u) rgrid = cus * 16u;
         if (rgrid > 131072u) rgrid = 131072u;
@@ -2553,7 +2563,7 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
 
     // Can the queue overflow at all?  Not when it holds every shadow ray of a round's records.
     const uint64_t rays_per_record = args.max_shadow_rays ? args.max_shadow_rays : 1u;
-    const bool can_overflow = (uint64_t)ws.cap_work * rays_per_record > ws.qcap;
+    const bool can_overflow = (uint64_t)cap_used * rays_per_record + (uint64_t)g.filter * w.qchunk > ws.qcap;
     const size_t npix = ws.npix;
     if (can_overflow) {
         // what a second rendering of this frame starts from: generator states, work counters, tallies
