@@ -376,8 +376,9 @@ def test_filter_decisions_agree_with_the_exact_test(kind):
 @pytest.mark.gpu
 def test_wavefront_redoes_a_round_when_the_ray_queue_overflows(oracle):
     """A glass sphere under the light leaves nearly every shadow ray undecided.  With a 1 MiB workspace
-    limit the undecided-ray queue holds 2^20 rays, the optimistic first filter launch overflows it and the
-    round is redone with worst-case launches; the image must not change."""
+    limit the undecided-ray queue holds 2^20 rays, the first rendering overflows it (the device drops rays and
+    raises a flag) and the frame is rendered again from the saved generator states with batched launches that
+    cannot overflow; image and end states must not change."""
     from cudaraytracer_amd import abi
 
     def scene(mod):

@@ -12,3 +12,9 @@ bash tools/prof_pmc4.sh ${TAG} >> gpurun_out/${TAG}_pmc_summary.txt 2>&1 || exit
 bash tools/prof_traffic.sh ${TAG} > gpurun_out/${TAG}_traffic.txt 2>&1 || exit 1
 cat gpurun_out/${TAG}_traffic.txt
 cat gpurun_out/${TAG}_kernel_stats.csv
+# what one rank of 2 / 4 / 8 runs (tools/shard_bench.py), kernel-trace stats only
+for W in 2 4 8; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_shard${W} -o kt -- python3 tools/shard_bench.py $W 1 10 > gpurun_out/${TAG}_shard${W}.log 2>&1 || exit 1
+  cp gpurun_out/${TAG}_shard${W}/kt_kernel_stats.csv gpurun_out/${TAG}_shard_1of${W}_kernel_stats.csv
+  cat gpurun_out/${TAG}_shard${W}.log | tail -1
+done
