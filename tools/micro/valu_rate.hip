@@ -1,4 +1,6 @@
-// Measures VALU issue rate on gfx950: plain v_fma_f32 vs v_pk_fma_f32, at 1..8 waves per SIMD.
+// Measures VALU issue rate on gfx950: plain v_fma_f32 vs v_pk_fma_f32 vs integer, at 1..8 waves per SIMD; modes 3-5:
+// the plain fma loop with only lanes 0..31, only the even lanes, only lanes 0..15 active (does a wave64 instruction
+// whose upper half is masked off issue in fewer cycles?).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float float2_ __attribute__((ext_vector_type(2)));
@@ -7,8 +9,11 @@ __global__ void __launch_bounds__(64) k(float* out, int iters, float s) {
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float2_ p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6};
     float2_ ss = {s, s};
+    if (MODE == 3 && threadIdx.x >= 32) iters = 0;
+    if (MODE == 4 && (threadIdx.x & 1)) iters = 0;
+    if (MODE == 5 && threadIdx.x >= 16) iters = 0;
     for (int i = 0; i < iters; ++i) {
-        if (MODE == 0) {
+        if (MODE == 0 || MODE >= 3) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 a0 = __builtin_fmaf(a0, s, a1); a1 = __builtin_fmaf(a1, s, a2); a2 = __builtin_fmaf(a2, s, a3); a3 = __builtin_fmaf(a3, s, a4);
@@ -35,14 +40,17 @@ int main() {
     float* out; hipMalloc(&out, 8192 * 64 * 4 * 2);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;
-    for (int mode = 0; mode < 3; ++mode)
+    for (int mode = 0; mode < 6; ++mode)
         for (int w : {1, 2, 4, 8}) {
             int grid = 256 * 4 * w;
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(e0);
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(64), 0, 0, out, iters, 0.999f);
                 else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(64), 0, 0, out, iters, 0.999f);
-                else hipLaunchKernelGGL(k<2>, dim3(grid), dim3(64), 0, 0, out, iters, 0.999f);
+                else if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(64), 0, 0, out, iters, 0.999f);
+                else if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(grid), dim3(64), 0, 0, out, iters, 0.999f);
+                else if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(grid), dim3(64), 0, 0, out, iters, 0.999f);
+                else hipLaunchKernelGGL(k<5>, dim3(grid), dim3(64), 0, 0, out, iters, 0.999f);
                 hipEventRecord(e1); hipEventSynchronize(e1);
             }
             float ms; hipEventElapsedTime(&ms, e0, e1);
