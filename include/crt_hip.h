@@ -177,7 +177,9 @@ int crt_rng_export(crt_ctx* ctx, uint32_t* host_state6);
 /* ---- render ------------------------------------------------------------- */
 /* Replaces renderWithCuda/render (main.cu:963-977, 328-347): renders every
  * pixel once into fb_dev (nx*ny RGBA float, row-major, index (j*nx+i)*4+c) and
- * advances the per-pixel RNG states. */
+ * advances the per-pixel RNG states.  Whether the call waits for the GPU depends
+ * on the pipeline (crt_set_pipeline); work queued later on `stream` sees the
+ * finished image either way. */
 int crt_render(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void* stream);
 /* crt_render for callers that cannot allocate device memory: code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same image and same RNG end
@@ -229,8 +231,12 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out);
  *                            or no device memory left for its workspace)
  *   CRT_PIPELINE_PERSISTENT  one persistent kernel per launch, asynchronous on `stream`, no workspace
  *   CRT_PIPELINE_WAVEFRONT   trace / filter / resolve / shade / sum kernels with records in device
- *                            memory; the call returns after the image is complete (it synchronises
- *                            `stream` at least once per round)
+ *                            memory, sized from device-side counters.  A frame of one round whose ray
+ *                            queue cannot overflow (gl_iter 0 at aa_iter <= 1) is asynchronous on
+ *                            `stream`; any other call returns after the image is complete (rounds are
+ *                            queued back to back, the host waits for the last one, and a frame that
+ *                            left more shadow rays undecided than the queue holds is rendered a second
+ *                            time from its saved generator states)
  * The reference has one kernel and no such switch (main.cu:328-347). */
 #define CRT_PIPELINE_AUTO 0
 #define CRT_PIPELINE_PERSISTENT 1
