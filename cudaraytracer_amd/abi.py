@@ -40,7 +40,7 @@ class crt_geometry(C.Structure):
 class crt_light(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("pos", C.c_float * 3), ("color", C.c_float * 4),
                 ("intensity", C.c_float), ("points", (C.c_float * 3) * 4), ("twoSided", C.c_uint32),
-                ("shadowSamples", C.c_uint32), ("initialized", C.c_uint32)]
+                ("shadowSamples", C.c_uint32), ("initialized", C.c_uint32), ("horizonClip", C.c_uint32)]
 
 
 class crt_camera(C.Structure):

@@ -106,6 +106,7 @@ crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
     for (uint32_t l = 0; l < ctx->scene_host.n_lights; ++l) {
         const crt::DevLight& L = ctx->scene_host.lights[l];
         if (L.kind == CRT_LIGHT_AREA && L.initialized) a.max_shadow_rays += L.shadow_samples;
+        if (L.kind == CRT_LIGHT_AREA && L.initialized && L.horizon_clip) a.horizon_clip = 1u;
     }
     return a;
 }

@@ -703,6 +703,54 @@ DI float ltc_polygon(const float* __restrict__ ltc2, V3 L0, V3 L1, V3 L2, V3 L3,
     return sum;
 }
 
+// AreaLight::_clipQuadToHorizon + the clipped branch of _evaluateLTC (AreaLight.hpp:104-214,298-334) on the four
+// transformed corners.  The reference never takes this branch (AreaLight::_clipless is true and has no setter);
+// crt_light::horizonClip selects it.  keep/drop: the edge from a vertex above the horizon to one below is cut at
+// z = 0, -drop.z * keep + keep.z * drop.
+DI V3 clip_edge(V3 keep, V3 drop) { return keep * (-drop.z) + drop * keep.z; }
+DI float ltc_polygon_clipped(V3 L0, V3 L1, V3 L2, V3 L3, bool two_sided) {
+    uint32_t config = 0;
+    if (L0.z > 0.0f) config += 1u;
+    if (L1.z > 0.0f) config += 2u;
+    if (L2.z > 0.0f) config += 4u;
+    if (L3.z > 0.0f) config += 8u;
+    V3 L4 = mk3(0.0f, 0.0f, 0.0f);
+    uint32_t n = 0;
+    switch (config) {
+    case 0: break;
+    case 1: n = 3; L1 = clip_edge(L0, L1); L2 = clip_edge(L0, L3); break;
+    case 2: n = 3; L0 = clip_edge(L1, L0); L2 = clip_edge(L1, L2); break;
+    case 3: n = 4; L2 = clip_edge(L1, L2); L3 = clip_edge(L0, L3); break;
+    case 4: n = 3; L0 = clip_edge(L2, L3); L1 = clip_edge(L2, L1); break;
+    case 5: break;
+    case 6: n = 4; L0 = clip_edge(L1, L0); L3 = clip_edge(L2, L3); break;
+    case 7: n = 5; L4 = clip_edge(L0, L3); L3 = clip_edge(L2, L3); break;
+    case 8: n = 3; L0 = clip_edge(L3, L0); L1 = clip_edge(L3, L2); L2 = L3; break;
+    case 9: n = 4; L1 = clip_edge(L0, L1); L2 = clip_edge(L3, L2); break;
+    case 10: break;
+    case 11: n = 5; L4 = L3; L3 = clip_edge(L3, L2); L2 = clip_edge(L1, L2); break;
+    case 12: n = 4; L1 = clip_edge(L2, L1); L0 = clip_edge(L3, L0); break;
+    case 13: n = 5; L4 = L3; L3 = L2; L2 = clip_edge(L2, L1); L1 = clip_edge(L0, L1); break;
+    case 14: n = 5; L4 = clip_edge(L3, L0); L0 = clip_edge(L1, L0); break;
+    default: n = 4; break; // 15: nothing below the horizon
+    }
+    if (n == 0u) return 0.0f;
+    if (n == 3u) L3 = L0;
+    if (n == 4u) L4 = L0;
+    L0 = ray_dir(L0); // "normalise unless shorter than 1e-4"
+    L1 = ray_dir(L1);
+    L2 = ray_dir(L2);
+    L3 = ray_dir(L3);
+    L4 = ray_dir(L4);
+    float sum = 0.0f;
+    sum += integrate_edge_vec(L0, L1).z;
+    sum += integrate_edge_vec(L1, L2).z;
+    sum += integrate_edge_vec(L2, L3).z;
+    if (n >= 4u) sum += integrate_edge_vec(L3, L4).z;
+    if (n == 5u) sum += integrate_edge_vec(L4, L0).z;
+    return two_sided ? __builtin_fabsf(sum) : max_std(0.0f, sum);
+}
+
 // main.cu:50-58
 DI void surface_frame(V3 n, V3& Nx, V3& Nz) {
     if (__builtin_fabsf(n.x) > __builtin_fabsf(n.y)) Nx = mk3(n.z, 0.0f, -n.x) * rsqrt_c(n.x * n.x + n.z * n.z);

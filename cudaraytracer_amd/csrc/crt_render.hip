@@ -80,6 +80,7 @@ __global__ void __launch_bounds__(64) random_init_kernel(uint32_t npix, uint64_t
 #ifndef CRT_WAVES_PER_EU
 #define CRT_WAVES_PER_EU 1
 #endif
+template <bool CLIP>
 __global__ void __launch_bounds__(64, CRT_WAVES_PER_EU) render_kernel(RenderArgs a) {
     ScenePtr sc = (ScenePtr)a.scene;
     const float* __restrict__ ltc = a.ltc;
@@ -628,7 +629,7 @@ __global__ void __launch_bounds__(64, CRT_WAVES_PER_EU) render_kernel(RenderArgs
             if (act) {
                 shadowed += s_shadow[lane];
                 float visibility = 1.0f - ((float)shadowed / (float)S);
-                direct = direct + area_light_shade(ltc, L, gs, n_P, n_N, n_view, visibility);
+                direct = direct + area_light_shade<CLIP>(ltc, L, gs, n_P, n_N, n_view, visibility);
             }
             __syncthreads(); // s_shadow is reset at the top of the next light
         }
@@ -711,7 +712,7 @@ hipError_t prime_render_grid() {
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (g_resident_waves[dev] == 0) {
         int per_cu = 0, cus = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, 64, 0);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false>, 64, 0);
         if (e != hipSuccess) return e;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;
@@ -731,7 +732,8 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream) {
     uint32_t grid = args.n_units < (uint32_t)g_resident_waves[dev] ? args.n_units : (uint32_t)g_resident_waves[dev];
     e = hipMemsetAsync(args.unit_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(render_kernel, dim3(grid), dim3(64), 0, stream, args);
+    if (args.horizon_clip) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(64), 0, stream, args);
+    else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(64), 0, stream, args);
     return hipGetLastError();
 }
 void launch_scatter(uint32_t nx, uint32_t ny, uint32_t tiles_x, uint32_t tiles_y, uint32_t world, uint32_t tiles_max,

@@ -179,6 +179,7 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
         d.two_sided = l.twoSided;
         d.shadow_samples = l.shadowSamples;
         d.initialized = l.initialized;
+        d.horizon_clip = l.horizonClip != 0u ? 1u : 0u;
         if (l.kind == CRT_LIGHT_AREA) {
             F3 pos = ld(l.pos);
             F3 p[4], w[4];
@@ -232,7 +233,7 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
                 continue;
             }
             if (!d.initialized) continue; // adds the ambient product wherever the point is (AreaLight.hpp:586)
-            if (d.two_sided || d.shadow_samples == 0u || !std::isfinite(d.intensity) || !finite3(d.color)) {
+            if (d.two_sided || d.horizon_clip || d.shadow_samples == 0u || !std::isfinite(d.intensity) || !finite3(d.color)) {
                 possible = false;
                 continue;
             }

@@ -103,7 +103,8 @@ struct alignas(64) DevLight {
     // negative zeros and NaNs, so that ambient + ((0 + 0) * intensity) * visibility is the ambient product bit
     // for bit.  Zero for every other light.
     uint32_t dark_lo, dark_hi;
-    uint32_t pad1[14];
+    uint32_t horizon_clip; // crt_light::horizonClip: the clipped branch of _evaluateLTC (AreaLight.hpp:298-334)
+    uint32_t pad1[13];
 };
 
 struct alignas(64) DevCamera {

@@ -41,7 +41,10 @@ DI PixelMap map_pixel(const RenderArgs& a, uint32_t unit, uint32_t idx) {
     return m;
 }
 
-// LTC part of AreaLight::calculateColor (AreaLight.hpp:595-649) once the visibility is known.
+// LTC part of AreaLight::calculateColor (AreaLight.hpp:595-649) once the visibility is known.  CLIP: the scene has
+// a light with crt_light::horizonClip set (a separate instantiation, so that kernels for ordinary scenes do not
+// carry the clipping code's registers).
+template <bool CLIP>
 DI V4 area_light_shade(const float* __restrict__ ltc, const DevLight CRT_CONST* L,
                        const DevGeomShade CRT_CONST* g, V3 P, V3 N, V3 view, float visibility) {
     V3 lcol = ld3c(L->color);
@@ -68,11 +71,11 @@ DI V4 area_light_shade(const float* __restrict__ ltc, const DevLight CRT_CONST* 
     V3 w0 = ld3c(L->pts[0]) - P, w1 = ld3c(L->pts[1]) - P, w2 = ld3c(L->pts[2]) - P, w3 = ld3c(L->pts[3]) - P;
     bool behind = dot3(w0, ld3c(L->light_normal)) < 0.0f;
     bool two_sided = L->two_sided != 0u;
+    const bool clip = CLIP && L->horizon_clip != 0u; // wave-uniform: the clipped branch of _evaluateLTC (AreaLight.hpp:298-334)
     // identity * transpose(T1,T2,N): rows T1, T2, N
-    float dsum = ltc_polygon(ltc2, mk3(dot3(T1, w0), dot3(T2, w0), dot3(N, w0)),
-                             mk3(dot3(T1, w1), dot3(T2, w1), dot3(N, w1)),
-                             mk3(dot3(T1, w2), dot3(T2, w2), dot3(N, w2)),
-                             mk3(dot3(T1, w3), dot3(T2, w3), dot3(N, w3)), behind, two_sided);
+    const V3 d0 = mk3(dot3(T1, w0), dot3(T2, w0), dot3(N, w0)), d1 = mk3(dot3(T1, w1), dot3(T2, w1), dot3(N, w1));
+    const V3 d2 = mk3(dot3(T1, w2), dot3(T2, w2), dot3(N, w2)), d3 = mk3(dot3(T1, w3), dot3(T2, w3), dot3(N, w3));
+    float dsum = clip ? ltc_polygon_clipped(d0, d1, d2, d3, two_sided) : ltc_polygon(ltc2, d0, d1, d2, d3, behind, two_sided);
     // Minv(t1) * transpose(T1,T2,N): row0 = t1.x*T1 + t1.z*N, row1 = T2, row2 = t1.y*T1 + t1.w*N
     // (mat3 product accumulates 0 + a*T1 + 0*T2 + c*N per entry, mat.hpp:1481-1492)
     V3 r0 = mk3((0.0f + t1.x * T1.x) + 0.0f * T2.x + t1.z * N.x, (0.0f + t1.x * T1.y) + 0.0f * T2.y + t1.z * N.y,
@@ -81,10 +84,9 @@ DI V4 area_light_shade(const float* __restrict__ ltc, const DevLight CRT_CONST* 
                 (0.0f + 0.0f * T1.z) + 1.0f * T2.z + 0.0f * N.z);
     V3 r2 = mk3((0.0f + t1.y * T1.x) + 0.0f * T2.x + t1.w * N.x, (0.0f + t1.y * T1.y) + 0.0f * T2.y + t1.w * N.y,
                 (0.0f + t1.y * T1.z) + 0.0f * T2.z + t1.w * N.z);
-    float ssum = ltc_polygon(ltc2, mk3(dot3(r0, w0), dot3(r1, w0), dot3(r2, w0)),
-                             mk3(dot3(r0, w1), dot3(r1, w1), dot3(r2, w1)),
-                             mk3(dot3(r0, w2), dot3(r1, w2), dot3(r2, w2)),
-                             mk3(dot3(r0, w3), dot3(r1, w3), dot3(r2, w3)), behind, two_sided);
+    const V3 s0 = mk3(dot3(r0, w0), dot3(r1, w0), dot3(r2, w0)), s1 = mk3(dot3(r0, w1), dot3(r1, w1), dot3(r2, w1));
+    const V3 s2 = mk3(dot3(r0, w2), dot3(r1, w2), dot3(r2, w2)), s3 = mk3(dot3(r0, w3), dot3(r1, w3), dot3(r2, w3));
+    float ssum = clip ? ltc_polygon_clipped(s0, s1, s2, s3, two_sided) : ltc_polygon(ltc2, s0, s1, s2, s3, behind, two_sided);
     V3 diffuse = (lcol * mk3(dsum, dsum, dsum)) * dcol;
     V3 spec = mk3(ssum, ssum, ssum) * (scol * t2.x + (mk3(1.0f, 1.0f, 1.0f) - scol) * t2.y);
     V3 specular = lcol * spec;

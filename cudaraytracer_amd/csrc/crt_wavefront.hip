@@ -1901,12 +1901,16 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
 // ---------------------------------------------------------------------------------------- shade
 // One block per 64 records; the grid covers the workspace's capacity and blocks beyond the round's record
 // count (read from the device counter) leave at once.
+// CLIP: some light takes the horizon-clipping LTC branch (crt_light::horizonClip).
+template <bool CLIP>
 DI void shade_record(const WfArgs& w, ScenePtr sc, uint32_t wi);
+template <bool CLIP>
 __global__ void __launch_bounds__(64, 4) wf_shade_kernel(WfArgs w) {
     const uint32_t wi = blockIdx.x * 64u + threadIdx.x;
     if (wi >= min(w.ctrs[WF_CTR_WORK], w.cap_work)) return;
-    shade_record(w, (ScenePtr)w.r.scene, wi);
+    shade_record<CLIP>(w, (ScenePtr)w.r.scene, wi);
 }
+template <bool CLIP>
 DI void shade_record(const WfArgs& w, ScenePtr sc, uint32_t wi) {
     const size_t cw = w.cap_work;
     const uint32_t* r = w.work + wi;
@@ -1942,7 +1946,7 @@ DI void shade_record(const WfArgs& w, ScenePtr sc, uint32_t wi) {
                            L->pos[0], L->pos[1], L->pos[2], shadowed, S);
             }
 #endif
-            direct = direct + area_light_shade(w.r.ltc, L, gs, P, N, view, visibility);
+            direct = direct + area_light_shade<CLIP>(w.r.ltc, L, gs, P, N, view, visibility);
         }
     }
     const V4 c = att * direct; // final_color += attenuation * light (main.cu:195)
@@ -2380,7 +2384,8 @@ hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const G
                 WF_TIMED(WF_K_RESOLVE, hipLaunchKernelGGL(wf_resolve_kernel, dim3(g.resolve), dim3(64), 0, stream, w));
             }
         }
-        WF_TIMED(WF_K_SHADE, hipLaunchKernelGGL(wf_shade_kernel, dim3(g.shade), dim3(64), 0, stream, w));
+        if (args.horizon_clip) WF_TIMED(WF_K_SHADE, hipLaunchKernelGGL(wf_shade_kernel<true>, dim3(g.shade), dim3(64), 0, stream, w));
+        else WF_TIMED(WF_K_SHADE, hipLaunchKernelGGL(wf_shade_kernel<false>, dim3(g.shade), dim3(64), 0, stream, w));
         if (args.n_units < 4096u) WF_TIMED(WF_K_SUM, hipLaunchKernelGGL(wf_sum_kernel<true>, dim3(args.n_units), dim3(64), 0, stream, w, first));
         else WF_TIMED(WF_K_SUM, hipLaunchKernelGGL(wf_sum_kernel<false>, dim3(args.n_units), dim3(64), 0, stream, w, first));
         e = hipGetLastError();

@@ -13,6 +13,7 @@ class AreaLight : public Light {
     vec3 _points[4] = {vec3(-1.f, -1.f, 0.f), vec3(-1.f, 1.f, 0.f), vec3(1.f, 1.f, 0.f), vec3(1.f, -1.f, 0.f)};
     bool _twoSided = false;
     bool _initialized = false;
+    bool _clipless = true; // no setter, as in the reference (AreaLight.hpp:42): the clipped branch is reachable through crt_light only
     unsigned int _shadowSamples = 10u;
 
     // Moves the light position to the centroid and makes the corners relative to it (AreaLight.hpp:56-70).
@@ -67,6 +68,7 @@ public:
         l.twoSided = _twoSided ? 1u : 0u;
         l.shadowSamples = _shadowSamples;
         l.initialized = _initialized ? 1u : 0u;
+        l.horizonClip = _clipless ? 0u : 1u;
         out.push_back(l);
     }
 };

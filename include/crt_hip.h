@@ -95,6 +95,10 @@ typedef struct crt_light {
     uint32_t twoSided;
     uint32_t shadowSamples;
     uint32_t initialized; /* AreaLight::_initialized (AreaLight.hpp:36,488,586): 0 -> ambient term only */
+    uint32_t horizonClip; /* !AreaLight::_clipless (AreaLight.hpp:42,245,298): 0 -> the clipless form-factor branch,
+                             which is what the reference always runs (_clipless is true and has no setter);
+                             1 -> clip the transformed quad to the horizon and sum the edge integrals
+                             (AreaLight.hpp:104-214,298-334) */
 } crt_light;
 
 #define CRT_CAM_ORTHOGRAPHIC 0u /* CameraType, Camera.hpp:19-22 */

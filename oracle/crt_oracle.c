@@ -452,13 +452,25 @@ static float reflectance_c(float cosine, float ri) {
     return r0 + (1.0f - r0) * ((x2 * x2) * x);
 }
 
-/* Texture::sample with CLAMP wrap, Texture.hpp:249-252,126-185,211-237 */
+/* One coordinate of Texture::_imageSpaceCoordinates, Texture.hpp:129-152 (wrap: 0 CLAMP, 1 MIRROR, 2 REPEAT,
+ * Texture.hpp:25-29; fract is x - floor(x), math_functions.hpp:94-97). */
+static float texture_wrap(float f, int wrap) {
+    if (!(f < 0.0f || f > 1.0f)) return f;
+    if (wrap == 0) return saturatef_c(f);
+    if (wrap == 2) return f - floorf(f);
+    return fabsf((f - floorf(f)) - 1.0f);
+}
+/* Texture::_imageSpaceCoordinates, Texture.hpp:126-185: the texel a uv pair reads. */
+void orc_texture_texel(float u, float v, int wrap_h, int wrap_v, uint32_t width, uint32_t height, uint32_t xy[2]) {
+    xy[0] = (uint32_t)(texture_wrap(u, wrap_h) * (float)(width - 1u));
+    xy[1] = (uint32_t)(texture_wrap(v, wrap_v) * (float)(height - 1u));
+}
+
+/* Texture::sample of an LTC table (64 x 64, CLAMP both ways: AreaLight.hpp:51-54), Texture.hpp:249-252,211-237 */
 static v4 ltc_sample(const float* tab, v2 uv) {
-    float fx = uv.x, fy = uv.y;
-    if (fx < 0.0f || fx > 1.0f) fx = saturatef_c(fx);
-    if (fy < 0.0f || fy > 1.0f) fy = saturatef_c(fy);
-    uint32_t x = (uint32_t)(fx * (float)(64u - 1u));
-    uint32_t y = (uint32_t)(fy * (float)(64u - 1u));
+    uint32_t xy[2];
+    orc_texture_texel(uv.x, uv.y, 0, 0, 64u, 64u, xy);
+    const uint32_t x = xy[0], y = xy[1];
     if (x >= 64u || y >= 64u) return V4(0, 0, 0, 0);
     size_t pos0 = ((size_t)y * 64u + (size_t)x) * 4u;
     return V4(tab[pos0], tab[pos0 + 1], tab[pos0 + 2], tab[pos0 + 3]);
@@ -579,7 +591,63 @@ static v3 integrate_edge_vec(v3 v1, v3 v2) {
     return v3_scale(v3_cross(v1, v2), ts);
 }
 
-/* AreaLight::_evaluateLTC, clipless branch, AreaLight.hpp:216-297,336 */
+/* AreaLight::_clipQuadToHorizon, AreaLight.hpp:104-214: clips the transformed quad against z = 0; returns the
+ * number of vertices (0, 3, 4 or 5) and closes the polygon (L[n] = L[0] for n = 3, 4). */
+static int clip_quad_to_horizon(v3 L[5]) {
+#define ORC_CLIP(keep, drop) v3_add(v3_scale(keep, -(drop).z), v3_scale(drop, (keep).z)) /* -drop.z * keep + keep.z * drop */
+    int config = 0;
+    if (L[0].z > 0.0f) config += 1;
+    if (L[1].z > 0.0f) config += 2;
+    if (L[2].z > 0.0f) config += 4;
+    if (L[3].z > 0.0f) config += 8;
+    int n = 0;
+    switch (config) {
+    case 0: break;
+    case 1: n = 3; L[1] = ORC_CLIP(L[0], L[1]); L[2] = ORC_CLIP(L[0], L[3]); break;
+    case 2: n = 3; L[0] = ORC_CLIP(L[1], L[0]); L[2] = ORC_CLIP(L[1], L[2]); break;
+    case 3: n = 4; L[2] = ORC_CLIP(L[1], L[2]); L[3] = ORC_CLIP(L[0], L[3]); break;
+    case 4: n = 3; L[0] = ORC_CLIP(L[2], L[3]); L[1] = ORC_CLIP(L[2], L[1]); break;
+    case 5: n = 0; break;
+    case 6: n = 4; L[0] = ORC_CLIP(L[1], L[0]); L[3] = ORC_CLIP(L[2], L[3]); break;
+    case 7: n = 5; L[4] = ORC_CLIP(L[0], L[3]); L[3] = ORC_CLIP(L[2], L[3]); break;
+    case 8: n = 3; L[0] = ORC_CLIP(L[3], L[0]); L[1] = ORC_CLIP(L[3], L[2]); L[2] = L[3]; break;
+    case 9: n = 4; L[1] = ORC_CLIP(L[0], L[1]); L[2] = ORC_CLIP(L[3], L[2]); break;
+    case 10: n = 0; break;
+    case 11: n = 5; L[4] = L[3]; L[3] = ORC_CLIP(L[3], L[2]); L[2] = ORC_CLIP(L[1], L[2]); break;
+    case 12: n = 4; L[1] = ORC_CLIP(L[2], L[1]); L[0] = ORC_CLIP(L[3], L[0]); break;
+    case 13: n = 5; L[4] = L[3]; L[3] = L[2]; L[2] = ORC_CLIP(L[2], L[1]); L[1] = ORC_CLIP(L[0], L[1]); break;
+    case 14: n = 5; L[4] = ORC_CLIP(L[3], L[0]); L[0] = ORC_CLIP(L[1], L[0]); break;
+    default: n = 4; break; /* 15: nothing below the horizon */
+    }
+#undef ORC_CLIP
+    if (n == 3) L[3] = L[0];
+    if (n == 4) L[4] = L[0];
+    return n;
+}
+
+/* The horizon-clipping branch of AreaLight::_evaluateLTC, AreaLight.hpp:298-334, on the transformed corners.
+ * The reference never takes it (AreaLight::_clipless is true and has no setter, AreaLight.hpp:42); crt_light's
+ * horizonClip selects it. */
+static float ltc_clipped_sum(const v3 corners[4], int two_sided) {
+    v3 L[5] = {corners[0], corners[1], corners[2], corners[3], V3(0, 0, 0)};
+    int n = clip_quad_to_horizon(L);
+    if (n == 0) return 0.0f; /* AreaLight.hpp:302-303 */
+    for (int i = 0; i < 5; ++i) L[i] = eps_equal(v3_length_sq(L[i]), 0.0f, EPS_SQ) ? L[i] : v3_normalize(L[i]);
+    float sum = 0.0f;
+    sum += integrate_edge_vec(L[0], L[1]).z;
+    sum += integrate_edge_vec(L[1], L[2]).z;
+    sum += integrate_edge_vec(L[2], L[3]).z;
+    if (n >= 4) sum += integrate_edge_vec(L[3], L[4]).z;
+    if (n == 5) sum += integrate_edge_vec(L[4], L[0]).z;
+    return two_sided ? fabsf(sum) : max_std(0.0f, sum);
+}
+/* Test hook: the clipped integral of four already transformed corners. */
+float orc_ltc_clipped(const float corners[4][3], int two_sided) {
+    v3 c[4] = {v3_from(corners[0]), v3_from(corners[1]), v3_from(corners[2]), v3_from(corners[3])};
+    return ltc_clipped_sum(c, two_sided);
+}
+
+/* AreaLight::_evaluateLTC, AreaLight.hpp:216-336 */
 static float evaluate_ltc(const ctx_t* cx, const crt_light* L, v3 norm, v3 view, v3 frag,
                           const m3* minV, const v3 pts[4]) {
     v3 T1 = v3_sub(view, v3_scale(norm, v3_dot(view, norm)));
@@ -589,6 +657,7 @@ static float evaluate_ltc(const ctx_t* cx, const crt_light* L, v3 norm, v3 view,
     m3 Minv = m3_mul(minV, &basis);
     v3 Lv[4];
     for (int i = 0; i < 4; ++i) Lv[i] = m3_mulv(&Minv, v3_sub(pts[i], frag));
+    if (L->horizonClip) return ltc_clipped_sum(Lv, L->twoSided != 0);
     v3 dir = v3_sub(pts[0], frag);
     v3 lightNormal = v3_cross(v3_sub(pts[1], pts[0]), v3_sub(pts[3], pts[0]));
     int behind = v3_dot(dir, lightNormal) < 0.0f;

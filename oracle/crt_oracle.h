@@ -49,6 +49,12 @@ int orc_render(const crt_scene_desc* sc, const crt_settings* st, uint64_t seed, 
 /* Canonical stand-in for __powf(x, y), x >= 0 (the point light's specular term, Light.hpp:173). */
 float orc_pow(float x, float y);
 
+/* The horizon-clipped LTC integral (AreaLight.hpp:104-214,298-334) of four transformed corners. */
+float orc_ltc_clipped(const float corners[4][3], int two_sided);
+
+/* Texture::_imageSpaceCoordinates (Texture.hpp:126-185): texel of (u, v); wrap 0 CLAMP, 1 MIRROR, 2 REPEAT. */
+void orc_texture_texel(float u, float v, int wrap_h, int wrap_v, uint32_t width, uint32_t height, uint32_t xy[2]);
+
 /* Function-level probes. */
 int orc_camera_ray(const crt_camera* cam, float x, float y, float w, float h, float o[3], float d[3]);
 int orc_world_hit(const crt_scene_desc* sc, const float o[3], const float d[3], float maxdist, orc_hit_record* out);

@@ -53,6 +53,9 @@ def lib():
                                      C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_world_hit.argtypes = [C.POINTER(abi.crt_scene_desc), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                     C.c_float, C.POINTER(orc_hit_record)]
+        L.orc_texture_texel.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32 * 2)]
+        L.orc_ltc_clipped.argtypes = [C.POINTER((C.c_float * 3) * 4), C.c_int]
+        L.orc_ltc_clipped.restype = C.c_float
         _lib = L
     return _lib
 

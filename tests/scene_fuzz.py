@@ -132,4 +132,11 @@ def random_scene(mod, seed, shadow_samples=6, wild=False):
                     pt[k] *= scale
         for k in range(3):
             cam.pos[k] *= scale
+    # every fourth scene: its area lights take the horizon-clipping LTC branch (a generator of its own, so that the
+    # scenes themselves stay what they were before this flag existed)
+    crng = np.random.default_rng(seed * 7919 + 13)
+    if crng.random() < 0.25:
+        for l in lights:
+            if l.kind == abi.CRT_LIGHT_AREA:
+                l.horizonClip = 1
     return mod.Scene(cam, geo, lights)

@@ -193,13 +193,28 @@ def _custom_scene(mod, kind):
         lights[0].twoSided = 1
     elif kind == "uninitialised_area_light":
         lights[0].initialized = 0
+    elif kind == "horizon_clip":
+        # the clipped branch of _evaluateLTC (AreaLight.hpp:298-334): the ceiling lies below the light's horizon
+        # (nothing left), walls and floor see it partly or whole
+        lights[0].horizonClip = 1
+    elif kind == "horizon_clip_two_lights":
+        lights[0].horizonClip = 1
+        second = abi.crt_light.from_buffer_copy(bytes(lights[0]))
+        second.pos[0], second.pos[1], second.pos[2] = -0.6, -0.2, -1.3
+        for k, (x, y, z) in enumerate([(-0.05, -0.3, 0.3), (0.05, -0.25, -0.3), (0.1, 0.3, -0.25), (-0.1, 0.25, 0.3)]):
+            second.points[k][0], second.points[k][1], second.points[k][2] = x, y, z   # upright, slightly twisted
+        second.twoSided = 1
+        second.intensity = 4.0
+        second.shadowSamples = 4
+        lights.append(second)
     else:
         raise ValueError(kind)
     return mod.Scene(cam, geo, lights)
 
 
 @pytest.mark.parametrize("kind,gl", [("orthographic", 0), ("point_light", 1), ("two_lights_two_sided", 1),
-                                     ("skewed_quads", 1), ("trapezoid", 1), ("uninitialised_area_light", 0)])
+                                     ("skewed_quads", 1), ("trapezoid", 1), ("uninitialised_area_light", 0),
+                                     ("horizon_clip", 1), ("horizon_clip_two_lights", 1)])
 def test_general_scenes_match_oracle(gpu_ctx, oracle, kind, gl):
     st = crt.make_settings(nx=40, ny=32, aa_iter=1, gl_iter=gl, ind_rays=6, shadowSamples=8)
     fb, state = _gpu_render(gpu_ctx, _custom_scene(crt, kind), st, 5)
