@@ -103,6 +103,7 @@ crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
     a.tiles_y = (st->ny + 7u) / 8u;
     a.world = 1;
     a.audit = ctx->audit ? 1u : 0u;
+    a.n_geom = ctx->scene_host.n_geom;
     for (uint32_t l = 0; l < ctx->scene_host.n_lights; ++l) {
         const crt::DevLight& L = ctx->scene_host.lights[l];
         if (L.kind == CRT_LIGHT_AREA && L.initialized) a.max_shadow_rays += L.shadow_samples;

@@ -23,6 +23,22 @@
 
 namespace crt {
 
+// Measuring aid (build with -DCRT_LANE_PROFILE): PROF_LANES(k) counts, per section k, how often a wave runs the
+// section and with how many active lanes; the trace launch prints the table (crt_wavefront.hip).
+#ifdef CRT_LANE_PROFILE
+static __device__ unsigned long long g_lane_prof[2 * 32];
+#define PROF_LANES(k)                                                                             \
+    do {                                                                                          \
+        const unsigned long long m_ = __ballot(1);                                                \
+        if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m_)) {                               \
+            atomicAdd(&g_lane_prof[2 * (k)], 1ull);                                               \
+            atomicAdd(&g_lane_prof[2 * (k) + 1], (unsigned long long)__popcll(m_));              \
+        }                                                                                         \
+    } while (0)
+#else
+#define PROF_LANES(k)
+#endif
+
 typedef const DevScene CRT_CONST* ScenePtr;
 typedef const float CRT_CONST* CFloatPtr;
 
@@ -329,6 +345,7 @@ DI bool sphere_t(V3 center, float radius_sq, V3 o, V3 d, float dd, float dist, f
     float c = dot3(L, L) - radius_sq;
     float discr = b * b - 4.0f * a * c;
     if (discr < 0.0f) return false;
+    PROF_LANES(15);
     float t0, t1;
     if (eps_equal(discr, 0.0f, kEps)) {
         t0 = t1 = -0.5f * (b / a);
@@ -368,6 +385,7 @@ DI bool quad_plane_t(V3 p, V3 d, V3 nor, float dist, float closest, float& t) {
     float lim = (dist > 0.0f && dist < closest) ? dist : closest;
     float m = (adn * lim) * 1.000001f;
     if (!same_sign && apn > m && m > 1e-30f && lim < 1e30f) return false; // t = |pn/dn| > lim
+    PROF_LANES(14);
     float tt = -(pn / dn);
     if (tt < 0.0f || (dist > 0.0f && tt > dist)) return false;
     t = tt;
@@ -531,8 +549,13 @@ DI Hit closest_hit(ScenePtr sc, V3 o, V3 d, float dist) {
             V3 p = o - go;
             hit = quad_plane_t(p, d, gn, dist, h.t, t);
             if (hit) {
+                PROF_LANES(5);
                 UVRec q = load_uv(&sc->uv[i]);
                 hit = quad_uv<false>(q, p, d, t, u, v);
+#ifdef CRT_DOUBLE_UV
+                float u2 = 0.0f, v2 = 0.0f;
+                if (quad_uv<false>(q, p, d, t * 1.0000001f, u2, v2) && u2 == 12345.0f) hit = false;
+#endif
             }
         }
         if (hit && !(t > h.t)) {
@@ -543,6 +566,66 @@ DI Hit closest_hit(ScenePtr sc, V3 o, V3 d, float dist) {
             h.v = v;
         }
     }
+    return h;
+}
+
+// closest_hit for the tree walk: a plane hit of a parallelogram is first classified by where the hit point lies
+// against the quad's extent on its two kept axes (DevGeomBox::half_out_t / half_in_t): clearly outside is the
+// reference's rejection (Quad.hpp:281), clearly inside an axis-aligned rectangle is its acceptance, and only the
+// band of 6e-5 of the scene size between the two runs the exact (u,v) solve inside the loop.  A lane's plane
+// hits are mostly rejections (the planes of the other walls), and each exact solve costs two divisions.  For an
+// accepted hit that was only classified, `uv_pending` is set and the caller computes (u,v) for the final hit
+// alone (they are needed for the shading normal, Quad.hpp:299-325).
+DI Hit closest_hit_classified(ScenePtr sc, V3 o, V3 d, float dist, bool& uv_pending) {
+    Hit h;
+    h.idx = -1;
+    h.mat_type = 0;
+    h.t = kFltMax;
+    h.u = 0.0f;
+    h.v = 0.0f;
+    bool pending = false;
+    const float dd = dot3(d, d);
+    const uint32_t n = sc->n_geom;
+    for (uint32_t i = 0; i < n; ++i) {
+        const DevGeomWalk CRT_CONST* g = &sc->walk[i]; // one 16-dword scalar load, nothing more inside the branches
+        const uint32_t kind = g->kind_mat & 0xffu, mat = g->kind_mat >> 8;
+        const V3 go = ld3c(g->o), gn = ld3c(g->n);
+        const V3 mid = ld3c(g->mid), half_out = ld3c(g->half_out_t), half_in = ld3c(g->half_in_t);
+        float t = 0.0f, u = 0.0f, v = 0.0f;
+        bool hit, deferred = false;
+        if (kind == CRT_GEOM_SPHERE) {
+            hit = sphere_t(go, gn.x, o, d, dd, dist, t);
+        } else {
+            V3 p = o - go;
+            hit = quad_plane_t(p, d, gn, dist, h.t, t);
+            if (hit) {
+                // |hit point - centre| per axis (fused: this is a classification with a margin, not the reference's arithmetic)
+                const float ax = __builtin_fabsf(__builtin_fmaf(d.x, t, o.x) - mid.x);
+                const float ay = __builtin_fabsf(__builtin_fmaf(d.y, t, o.y) - mid.y);
+                const float az = __builtin_fabsf(__builtin_fmaf(d.z, t, o.z) - mid.z);
+                const bool outside = (ax > half_out.x) | (ay > half_out.y) | (az > half_out.z);
+                const bool inside = (ax < half_in.x) & (ay < half_in.y) & (az < half_in.z);
+                if (outside) {
+                    hit = false;
+                } else if (inside) {
+                    deferred = true;
+                } else {
+                    PROF_LANES(5);
+                    UVRec q = load_uv(&sc->uv[i]);
+                    hit = quad_uv<false>(q, p, d, t, u, v);
+                }
+            }
+        }
+        if (hit && !(t > h.t)) {
+            h.idx = (int)i;
+            h.mat_type = mat;
+            h.t = t;
+            h.u = u;
+            h.v = v;
+            pending = deferred;
+        }
+    }
+    uv_pending = pending;
     return h;
 }
 

@@ -30,6 +30,7 @@ struct RenderArgs {
     uint32_t tx, ty, blocks_x, blocks_y, win_bx, win_by, start_bx, start_by; // MODE_PARTIAL
     uint32_t audit;           // wavefront pipeline: also run the filter audit kernel
     uint32_t max_shadow_rays; // shadow rays one diffuse hit casts: sum of shadowSamples over initialised area lights
+    uint32_t n_geom;          // primitives in the scene (sizes the trace kernel's LDS table)
     uint32_t horizon_clip;    // some light takes the horizon-clipping LTC branch (crt_light::horizonClip)
     uint32_t cooperative;     // wavefront pipeline: per mille of the work units (most expensive first) whose last GI
                               // level the trace kernel expands with one lane per child ray; 0 = none, 1000 = all

@@ -376,8 +376,21 @@ int flatten_scene(const crt_scene_desc* in, DevScene* out, char* err, size_t err
             b.half_out[k] = bounded ? 0.5f * (b.hi[k] - b.lo[k]) : INFINITY;
             const bool inner = b.lo_in[0] < INFINITY; // rectangle with an inner box
             b.half_in[k] = !inner ? -1.0f : (bounded ? 0.5f * (b.hi_in[k] - b.lo_in[k]) : INFINITY);
+            // lo/hi are the extent widened by 1e-3 rabs, lo_in/hi_in the extent shrunk by it
+            const double tight = 3e-5 * rabs, wide_margin = 1e-3 * rabs;
+            b.half_out_t[k] = bounded ? (float)((double)b.half_out[k] - wide_margin + tight) : INFINITY;
+            b.half_in_t[k] = !inner ? -1.0f : (bounded ? (float)((double)b.half_in[k] + wide_margin - tight) : INFINITY);
         }
-        for (int k = 0; k < 7; ++k) b.pad2[k] = 0.0f;
+        b.pad2 = 0.0f;
+        DevGeomWalk& wk = out->walk[i];
+        wk.kind_mat = out->hot[i].kind | (out->hot[i].mat_type << 8);
+        for (int k = 0; k < 3; ++k) {
+            wk.o[k] = out->hot[i].o[k];
+            wk.n[k] = out->hot[i].n[k];
+            wk.mid[k] = b.mid[k];
+            wk.half_out_t[k] = b.half_out_t[k];
+            wk.half_in_t[k] = b.half_in_t[k];
+        }
     }
     for (uint32_t g = 0; g < CRT_MAX_GEOMETRY; ++g) {
         out->interior_lo[g] = out->interior_hi[g] = 0xffffffffu;

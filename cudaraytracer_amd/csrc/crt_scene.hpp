@@ -33,6 +33,14 @@ struct alignas(32) DevGeomHot {
     float n[3];        // quad: nor = (v1-v0) x (v3-v0) (Quad.hpp:205-220); sphere: {radius^2, 0, 0} (Sphere.hpp:56)
 };
 
+// What the tree walk's closest-hit loop reads of a primitive, in one 16-dword scalar load: the hot record plus
+// the centre and half-widths that classify a plane hit (DevGeomBox::mid, half_out_t, half_in_t).
+struct alignas(64) DevGeomWalk {
+    uint32_t kind_mat; // DevGeomHot::kind | mat_type << 8
+    float o[3], n[3];  // DevGeomHot::o, n
+    float mid[3], half_out_t[3], half_in_t[3];
+};
+
 struct alignas(16) DevGeomUV { // quad only (Quad.hpp:232-250): everything that depends only on the vertices
     uint32_t idu, idv;         // the two kept axes (lut {1,2,0,1})
     uint32_t linear;           // |k2| < 1e-4 -> linear branch (Quad.hpp:255)
@@ -60,7 +68,11 @@ struct alignas(64) DevGeomBox {
     // The same boxes as centre and half-widths: |x - mid| > half_out rejects, |x - mid| < half_in is
     // inside the rectangle.  Unused axes: mid 0, half-widths +inf; no inner box: half_in -1.
     float mid[3], half_out[3], half_in[3];
-    float pad2[7];
+    // The same two tests with a margin of 3e-5 of the scene size instead of 1e-3 (still 30x the rounding of a hit
+    // point and of the (u,v) solve): the closest-hit loop of the tree walk decides most plane hits with them and
+    // leaves the exact (u,v) test to the narrow band in between.
+    float half_out_t[3], half_in_t[3];
+    float pad2;
 };
 
 struct alignas(16) DevGeomShade {
@@ -141,6 +153,7 @@ struct alignas(64) DevScene {
     uint32_t quad_par[CRT_MAX_LIGHTS][CRT_MAX_GEOMETRY];
     float cull_side[CRT_MAX_LIGHTS][CRT_MAX_GEOMETRY];
     float cull_thr[CRT_MAX_LIGHTS][CRT_MAX_GEOMETRY];
+    DevGeomWalk walk[CRT_MAX_GEOMETRY];
 };
 
 // Returns CRT_OK or CRT_ERR_INVALID (message in err, if non-null).

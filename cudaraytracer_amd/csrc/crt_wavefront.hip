@@ -851,10 +851,12 @@ DI void child_ray(V3 hp, V3 hn, V4 patt, V4 pdiff, float r1, float r2, float inv
 // What the tree walk reads of a primitive by per-lane index, copied to LDS once per workgroup: a lone
 // wave spends most of a step waiting, and an LDS read returns in a quarter of the time of a cached
 // global one.  Row layout: vertex normals [0..11], Material::diffuse [12..15], refractIndex [16],
-// kind [17], sphere centre [18..20], Material::ambient rgb [21..23].
-constexpr uint32_t kPrimWords = 24;
-typedef float PrimTable[CRT_MAX_GEOMETRY][kPrimWords];
-DI void fill_prim_table(ScenePtr sc, PrimTable& t, uint32_t tid, uint32_t nthreads) {
+// kind [17], sphere centre / quad corner 0 [18..20], Material::ambient rgb [21..23], the quad's (u,v) constants
+// (DevGeomUV: idu, idv, linear, nor_id, ka, kb, kg, k2) [24..34].
+constexpr uint32_t kPrimWords = 36;
+typedef float PrimRow[kPrimWords];
+typedef const PrimRow* PrimTable; // n_geom rows
+DI void fill_prim_table(ScenePtr sc, PrimRow* t, uint32_t tid, uint32_t nthreads) {
     const uint32_t n = sc->n_geom;
     for (uint32_t k = tid; k < n * kPrimWords; k += nthreads) {
         const uint32_t i = k / kPrimWords, wd = k % kPrimWords;
@@ -864,25 +866,55 @@ DI void fill_prim_table(ScenePtr sc, PrimTable& t, uint32_t tid, uint32_t nthrea
         else if (wd == 16u) v = sc->shade[i].refract_index;
         else if (wd == 17u) v = u2f(sc->hot[i].kind);
         else if (wd < 21u) v = sc->hot[i].o[wd - 18u];
-        else v = sc->shade[i].ambient[wd - 21u];
+        else if (wd < 24u) v = sc->shade[i].ambient[wd - 21u];
+        else if (wd == 24u) v = u2f(sc->uv[i].idu);
+        else if (wd == 25u) v = u2f(sc->uv[i].idv);
+        else if (wd == 26u) v = u2f(sc->uv[i].linear);
+        else if (wd == 27u) v = sc->uv[i].nor_id;
+        else if (wd < 30u) v = sc->uv[i].ka[wd - 28u];
+        else if (wd < 32u) v = sc->uv[i].kb[wd - 30u];
+        else if (wd < 34u) v = sc->uv[i].kg[wd - 32u];
+        else if (wd == 34u) v = sc->uv[i].k2;
         t[i][wd] = v;
     }
 }
 
 // One pop of color()'s loop (main.cu:132-221) for a ray with bounces left, without the shading.
 enum : uint32_t { POP_MISS = 0, POP_DIFFUSE = 1, POP_BOUNCE = 2 };
-DI uint32_t pop_ray(ScenePtr sc, const PrimTable& prim, V3& cur_o, V3& cur_d, V4& cur_att, uint32_t& cur_ref, V3& ray_d,
+DI uint32_t pop_ray(ScenePtr sc, PrimTable prim, V3& cur_o, V3& cur_d, V4& cur_att, uint32_t& cur_ref, V3& ray_d,
                     V3& P, V3& N, uint32_t& geom) {
     if (!eps_equal(len_sq(cur_d), 0.0f, kEpsSq)) ray_d = normalize3(cur_d);
     const V3 ro = cur_o;
+    bool uv_pending = false;
+#ifdef CRT_NO_CLASSIFY
     Hit h = closest_hit(sc, ro, ray_d, 0.0f);
+#else
+    Hit h = closest_hit_classified(sc, ro, ray_d, 0.0f, uv_pending);
+#endif
     if (h.idx < 0) return POP_MISS;
     const float* pr = prim[h.idx];
+    if (uv_pending) { // the final hit was accepted by where its point lies: its (u,v) for the normal below
+        UVRec q;
+        q.idu = f2u(pr[24]);
+        q.idv = f2u(pr[25]);
+        q.linear = f2u(pr[26]);
+        q.nor_id = pr[27];
+        q.ka[0] = pr[28];
+        q.ka[1] = pr[29];
+        q.kb[0] = pr[30];
+        q.kb[1] = pr[31];
+        q.kg[0] = pr[32];
+        q.kg[1] = pr[33];
+        q.k2 = pr[34];
+        (void)quad_uv<false>(q, ro - mk3(pr[18], pr[19], pr[20]), ray_d, h.t, h.u, h.v);
+    }
     // hit point and shading normal (Sphere.hpp:102-107, Quad.hpp:299-325)
     P = ro + ray_d * h.t;
     if (f2u(pr[17]) == CRT_GEOM_SPHERE) {
+        PROF_LANES(6);
         N = normalize3(P - mk3(pr[18], pr[19], pr[20]));
     } else {
+        PROF_LANES(7);
         const float u = h.u, v = h.v;
         const float l0 = (1 - u) * (1 - v), l1 = u * (1 - v), l2 = u * v, l3 = (1 - u) * v;
         N = V3{l0 * pr[0] + l1 * pr[3] + l2 * pr[6] + l3 * pr[9], l0 * pr[1] + l1 * pr[4] + l2 * pr[7] + l3 * pr[10],
@@ -891,6 +923,7 @@ DI uint32_t pop_ray(ScenePtr sc, const PrimTable& prim, V3& cur_o, V3& cur_d, V4
     geom = (uint32_t)h.idx;
     if (h.mat_type == CRT_MAT_DIFFUSE) return POP_DIFFUSE;
     if (h.mat_type == CRT_MAT_REFLECT) {
+        PROF_LANES(8);
         // get_reflect_ray (main.cu:76-81)
         V3 I = normalize3(ray_d);
         V3 rdir = reflect3(I, normalize3(N));
@@ -898,6 +931,7 @@ DI uint32_t pop_ray(ScenePtr sc, const PrimTable& prim, V3& cur_o, V3& cur_d, V4
         cur_d = rdir;
     } else {
         // get_refraction_ray (main.cu:83-108)
+        PROF_LANES(9);
         bool front_face = dot3(ray_d, N) < 0.0f;
         V3 norm = front_face ? N : neg(N);
         float ratio = pr[16] / 1.0f;
@@ -924,7 +958,7 @@ DI uint32_t pop_ray(ScenePtr sc, const PrimTable& prim, V3& cur_o, V3& cur_d, V4
 // hit still counts as a shaded point and still moves the generator past its light samples; it just writes
 // attenuation x that sum into its result slot now instead of becoming a record.  Returns false when some
 // light needs the full evaluation.
-DI bool ambient_only(ScenePtr sc, const PrimTable& prim, V3 P, uint32_t geom, V4 att, float4& out) {
+DI bool ambient_only(ScenePtr sc, PrimTable prim, V3 P, uint32_t geom, V4 att, float4& out) {
     if (sc->dark_possible == 0u) return false;
     const float* pr = prim[geom];
     const V3 mat_ambient = mk3(pr[21], pr[22], pr[23]);
@@ -950,6 +984,7 @@ DI bool ambient_only(ScenePtr sc, const PrimTable& prim, V3 P, uint32_t geom, V4
 // Stores one shade record.
 DI void store_record(const WfArgs& w, uint32_t wi, V3 P, V3 N, V3 view, V4 att, uint32_t geom, const Rng& rng, uint32_t slot,
                      uint32_t ordinal = 0u) {
+    PROF_LANES(11);
     if (wi < w.cap_work) {
         uint32_t* r = w.work + wi;
         const size_t cw = w.cap_work;
@@ -1056,7 +1091,7 @@ __global__ void __launch_bounds__(64) wf_cost_kernel(WfArgs w, uint32_t* unit_co
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
     const uint32_t lane = threadIdx.x, unit = blockIdx.x;
-    __shared__ PrimTable s_prim;
+    __shared__ __attribute__((aligned(16))) PrimRow s_prim[CRT_MAX_GEOMETRY];
     fill_prim_table(sc, s_prim, lane, 64u);
     __syncthreads();
     const PixelMap pm = map_pixel(a, unit, lane);
@@ -1105,13 +1140,21 @@ __global__ void __launch_bounds__(64) wf_cost_kernel(WfArgs w, uint32_t* unit_co
     if (lane == 0) unit_cost[unit] = f2u(cost);
 }
 
+#ifdef CRT_TRACE_MAXWAVES
+#define CRT_TRACE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(CRT_TRACE_MAXWAVES, CRT_TRACE_MAXWAVES)))
+#else
+#define CRT_TRACE_WAVES_ATTR
+#endif
 template <bool COOP>
-__global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w, uint32_t first, uint32_t slot_begin,
+__global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w, uint32_t first, uint32_t slot_begin,
                                                                                    uint32_t slot_end) {
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
     __shared__ __attribute__((aligned(16))) uint32_t s_jump[2][kJumpWords];
-    __shared__ PrimTable s_prim;
+    // one row per primitive of the scene (dynamic, sized by the launch): with the two jump tables the workgroup
+    // stays under 32 KB for scenes of up to 49 primitives, so that five workgroups fit a CU's LDS
+    extern __shared__ __attribute__((aligned(16))) float s_prim_words[];
+    PrimRow* s_prim = reinterpret_cast<PrimRow*>(s_prim_words);
     for (uint32_t k = threadIdx.x; k < 2u * kJumpWords; k += 64u * kTraceWaves)
         s_jump[k / kJumpWords][k % kJumpWords] = w.jump_tabs[k];
     fill_prim_table(sc, s_prim, threadIdx.x, 64u * kTraceWaves);
@@ -1233,8 +1276,10 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
         V4 n_att = V4{0, 0, 0, 0};
         uint32_t n_geom = 0, n_depth = 0;
         if (go) {
+            PROF_LANES(0);
             if (!cur_valid) {
                 if (!color_active) {
+                    PROF_LANES(1);
                     if (!task_active && aa_top != 0u) { // next task of aa_color's list
                         --aa_top;
                         t_cx = u2f(aa_stack[(3u * aa_top + 0u) * n_lp]);
@@ -1295,6 +1340,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
                     } else {
                         // pop the next child of the innermost frame (children leave last-to-first); its two
                         // draws are the last ones before the frame's generator state
+                        PROF_LANES(2);
                         Rng rv;
                         rv.v0 = f[(FR_RNG + 0) * n_lp];
                         rv.v1 = f[(FR_RNG + 1) * n_lp];
@@ -1337,6 +1383,7 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
                 // ---- pop (main.cu:132-147)
                 cur_valid = false;
                 if (cur_ref != 0u) {
+                    PROF_LANES(3);
                     const V3 view = neg(cur_d); // viewDir = -state.r_dir, the stored (un-normalised) direction
                     const V4 att = cur_att;
                     V3 P = mk3(0, 0, 0), N = mk3(0, 0, 0);
@@ -1381,14 +1428,24 @@ __global__ void __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w,
             uint32_t my_wi = 0;
             if (rm != 0) my_wi = reserve_records(w, wc, rm, lane);
             if (emit) {
+                PROF_LANES(10);
                 if (dark) w.contrib[(size_t)cnt * n_lp + lp] = dark_c;
+#ifdef CRT_ABLATE_STORE
+                else if (n_P.x == 1234.5f) store_record(w, my_wi, n_P, n_N, n_view, n_att, n_geom, rng, (uint32_t)((size_t)cnt * n_lp + lp));
+#else
                 else store_record(w, my_wi, n_P, n_N, n_view, n_att, n_geom, rng, (uint32_t)((size_t)cnt * n_lp + lp));
+#endif
                 ++cnt;
                 ++cnt_shade;
                 // the light samples of this hit (drawn by the filter kernel from the recorded state)
+#ifdef CRT_ABLATE_JUMP
+                rng.d += skip_draws * 362437u; rng.v0 ^= rng.v1 + rng.d;
+#else
                 if (skip_draws != 0u && skip_draws == w.jump_n[0]) rng_jump(rng, s_jump[0], skip_draws * 362437u);
                 else for (uint32_t k = 0; k < skip_draws; ++k) rng_step(rng);
+#endif
                 if (n_depth > 0u) {
+                    PROF_LANES(13);
                     ++cnt_expand;
                     // The reference draws (r1,r2) for every child and pushes while its stack has room (main.cu:176-191).
                     uint32_t room = on_stack < CRT_RAY_STACK ? CRT_RAY_STACK - on_stack : 0u;
@@ -2309,6 +2366,7 @@ hipError_t launch_trace(const RenderArgs& args, WfWorkspace& ws, const WfArgs& w
     hipError_t e = hipSuccess;
     EventTimer::Span* span = timer ? timer->begin(WF_K_TRACE, stream) : nullptr;
     const dim3 tblock(64 * kTraceWaves);
+    const uint32_t prim_lds = (args.n_geom ? args.n_geom : 1u) * (uint32_t)sizeof(PrimRow); // the kernel's primitive table
     const uint32_t rest = args.n_units - n_coop;
     hipStream_t cstream = stream;
     if (n_coop != 0u && rest != 0u) {
@@ -2318,10 +2376,10 @@ hipError_t launch_trace(const RenderArgs& args, WfWorkspace& ws, const WfArgs& w
         if (e != hipSuccess) return e;
     }
     if (n_coop != 0u)
-        hipLaunchKernelGGL(wf_trace_kernel<true>, dim3((n_coop * kCoopSplit + kTraceWaves - 1u) / kTraceWaves), tblock, 0,
+        hipLaunchKernelGGL(wf_trace_kernel<true>, dim3((n_coop * kCoopSplit + kTraceWaves - 1u) / kTraceWaves), tblock, prim_lds,
                            cstream, w, first, 0u, n_coop);
     if (rest != 0u)
-        hipLaunchKernelGGL(wf_trace_kernel<false>, dim3((rest + kTraceWaves - 1u) / kTraceWaves), tblock, 0, stream, w, first,
+        hipLaunchKernelGGL(wf_trace_kernel<false>, dim3((rest + kTraceWaves - 1u) / kTraceWaves), tblock, prim_lds, stream, w, first,
                            n_coop, args.n_units);
     if (cstream != stream) {
         e = hipEventRecord(static_cast<hipEvent_t>(ws.join_event), cstream);
@@ -2359,6 +2417,22 @@ hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const G
         if (e != hipSuccess) return e;
         e = launch_trace(args, ws, w, first, n_coop, stream, timer);
         if (e != hipSuccess) return e;
+#ifdef CRT_LANE_PROFILE
+        {
+            unsigned long long prof[64];
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_lane_prof), sizeof prof);
+            static const char* names[32] = {"iteration (lanes walking)", "next sample / end of call", "child pop", "pop_ray", "", "quad uv test",
+                                            "sphere normal", "quad normal", "reflect", "refract", "emit", "store_record", "", "frame push",
+                                            "plane division", "sphere roots"};
+            for (int k = 0; k < 32; ++k)
+                if (prof[2 * k] != 0ull)
+                    printf("lanes: section %2d %-28s runs %12llu  mean active lanes %.1f\n", k, names[k] ? names[k] : "", prof[2 * k],
+                           (double)prof[2 * k + 1] / (double)prof[2 * k]);
+            unsigned long long zero[64] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lane_prof), zero, sizeof zero);
+        }
+#endif
         if (!safe) {
             if (coop) WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel<true>, dim3(g.filter), dim3(64), 0, stream, w, 0u, kFromCounter));
             else WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel<false>, dim3(g.filter), dim3(64), 0, stream, w, 0u, kFromCounter));
