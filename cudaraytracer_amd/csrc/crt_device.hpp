@@ -649,12 +649,14 @@ DI Hit closest_hit_masked(ScenePtr sc, V3 o, V3 d, float dist, uint64_t mask) {
         float t = 0.0f, u = 0.0f, v = 0.0f;
         bool hit = false;
         if (mine) {
+            PROF_LANES(16);
             if (kind == CRT_GEOM_SPHERE) {
                 hit = sphere_t(go, gn.x, o, d, dd, dist, t);
             } else {
                 V3 p = o - go;
                 hit = quad_plane_t(p, d, gn, dist, h.t, t);
                 if (hit) {
+                    PROF_LANES(17);
                     UVRec q = load_uv(&sc->uv[i]);
                     hit = quad_uv<false>(q, p, d, t, u, v);
                 }
@@ -694,6 +696,7 @@ DI void hit_point_normal(ScenePtr sc, const Hit& h, V3 o, V3 d, V3& P, V3& N) {
 DI bool covered_through_glass(ScenePtr sc, const DevLight CRT_CONST* L, V3 o, V3 d, Hit h) {
     // The do/while of the reference runs at most `iterations` = 10 passes; pass 0 found h.
     for (unsigned i = 0;;) {
+        PROF_LANES(18);
         V3 P, N;
         hit_point_normal(sc, h, o, d, P, N);
         bool front_face = dot3(d, N) < 0.0f;

@@ -1920,6 +1920,7 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
             const DevLight CRT_CONST* L = &sc->lights[li];
             const LightC lc = load_lightc(L);
             if (mine) {
+                PROF_LANES(19);
                 float x;
                 shadow_ray(lc, P, u, v, o, d, x);
                 // first pass of Light::_isCovered (Light.hpp:35-46)
@@ -2424,7 +2425,8 @@ hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const G
             (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_lane_prof), sizeof prof);
             static const char* names[32] = {"iteration (lanes walking)", "next sample / end of call", "child pop", "pop_ray", "", "quad uv test",
                                             "sphere normal", "quad normal", "reflect", "refract", "emit", "store_record", "", "frame push",
-                                            "plane division", "sphere roots"};
+                                            "plane division", "sphere roots", "resolve: primitive test", "resolve: quad uv", "glass walk step",
+                                            "resolve: ray"};
             for (int k = 0; k < 32; ++k)
                 if (prof[2 * k] != 0ull)
                     printf("lanes: section %2d %-28s runs %12llu  mean active lanes %.1f\n", k, names[k] ? names[k] : "", prof[2 * k],
