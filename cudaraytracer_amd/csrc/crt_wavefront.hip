@@ -1145,8 +1145,11 @@ __global__ void __launch_bounds__(64) wf_cost_kernel(WfArgs w, uint32_t* unit_co
 #else
 #define CRT_TRACE_WAVES_ATTR
 #endif
+#ifndef CRT_COOP_WAVES
+#define CRT_COOP_WAVES 4
+#endif
 template <bool COOP>
-__global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, 4) wf_trace_kernel(WfArgs w, uint32_t first, uint32_t slot_begin,
+__global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? CRT_COOP_WAVES : 4) wf_trace_kernel(WfArgs w, uint32_t first, uint32_t slot_begin,
                                                                                    uint32_t slot_end) {
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
