@@ -150,8 +150,8 @@ def config5(args, torch, crt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["gl0", "gl1", "gl2", "gl3", "c5"], default="gl1",
                     help="README benchmark row; gl3 takes about 80 s per step on one GPU; c5 = BASELINE's last "
                          "configuration (aa_iter 4, gl_iter 3), measured on a sample and extrapolated (minutes)")

@@ -1,10 +1,12 @@
 """Pins the CPU restatement (oracle/) before anything is compared against it.
 
-Sources of truth, in order of strength:
+What it is pinned to:
+  * tests/golden/render0.hdr and reference_hdr_stats.json -- the reference's committed renders (unknown seed,
+    --use_fast_math build, 8-bit RGBE), hence statistical: gl_iter 0 here, gl_iter 2 and 3 through the HIP path in
+    tests/test_gpu_reference_renders.py (the HIP path equals this restatement bit for bit);
   * tests/golden/survey_anchors.json -- known-answer RNG values and seed-1234 images recorded from the
-    reference's own headers compiled for the host (IEEE arithmetic);
-  * tests/golden/render0.hdr and reference_hdr_stats.json -- the reference's committed renders (unknown
-    seed, --use_fast_math build, 8-bit RGBE), hence statistical.
+    reference's headers compiled for the host with stand-ins for what the image lacks: it corroborates, it is
+    not the reference's own output.
 Bit-parity with real cuRAND output stays unpinned: no artefact of the reference records a seed.
 """
 import ctypes as C
