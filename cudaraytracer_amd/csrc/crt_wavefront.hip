@@ -783,7 +783,10 @@ DI uint32_t record_light_class(ScenePtr sc, uint32_t li, const LightF& lf, V3 P)
 }
 
 // ---------------------------------------------------------------------------------------- trace
-constexpr uint32_t kTraceWaves = 4; // waves per trace workgroup (they share the generator jump tables in LDS)
+#ifndef CRT_TRACE_BLOCK_WAVES
+#define CRT_TRACE_BLOCK_WAVES 4
+#endif
+constexpr uint32_t kTraceWaves = CRT_TRACE_BLOCK_WAVES; // waves per trace workgroup (they share the generator jump tables in LDS)
 // Cooperative expansion handles at most 63 children at a time.  The k-th diffuse hit of a batch starts k
 // shaded points' worth of draws after the batch's first; its record keeps the batch's generator state
 // and k (bits 8..13 of the primitive word), and whoever draws from it (the filter kernel, for the fifth
