@@ -120,8 +120,11 @@ DI float dot3(V3 a, V3 b) {
 }
 DI float len_sq(V3 a) { return dot3(a, a); }
 DI float rsqrt_c(float x) { return rcp_exact(__builtin_sqrtf(x)); } // rsqrtf in IEEE form
-// vec::length (vec.hpp:398-409) = 1 / rsqrt(len^2) and vec::normalize (vec.hpp:411-422) = v * (1/len),
-// evaluated as the reference does: sqrt, then three dependent reciprocals.  One range test on
+// vec::length (vec.hpp:398-409) = 1 / rsqrt(len^2) and vec::normalize (vec.hpp:411-422) = v * (1/len): the
+// reference takes a square root and then three dependent reciprocals, s -> r1 = 1/s -> len = 1/r1 -> 1/len.
+// Under round-to-nearest the third one returns the first: 1/(1/(1/s)) == 1/s for every binary32 s whose chain
+// stays in the normal range (all 2^24 significands checked on the host, all bit patterns by crt_selftest_rcp on
+// the device; 1/(1/s) == s fails for a sixth of them, so `len` keeps its two reciprocals).  One range test on
 // len^2 covers the whole chain (len^2 in [2^-80, 2^80] keeps every intermediate in [2^-40, 2^40]).
 __device__ __attribute__((noinline)) float length_slow(float lsq) { return 1.0f / (1.0f / __builtin_sqrtf(lsq)); }
 DI float length_from_sq(float lsq) {
@@ -139,8 +142,9 @@ DI V3 div_s(V3 a, float y) {
 DI V3 normalize3_len(V3 a, float& len) {
     float lsq = len_sq(a);
     if (lsq >= 0x1p-80f && lsq <= 0x1p80f) {
-        len = rcp_nr(rcp_nr(sqrt_nr(lsq)));
-        return a * rcp_nr(len);
+        const float r1 = rcp_nr(sqrt_nr(lsq));
+        len = rcp_nr(r1);
+        return a * r1; // r1 == 1/len, see above
     }
     len = length_slow(lsq);
     if (len == 0.0f) return a;
@@ -787,6 +791,129 @@ DI float ltc_polygon(const float* __restrict__ ltc2, V3 L0, V3 L1, V3 L2, V3 L3,
     float sum = len * scale;
     if (!behind && !two_sided) sum = 0.0f;
     return sum;
+}
+
+// Out-of-line copy for the few shaded points the paired form below hands back.
+__device__ __attribute__((noinline)) float ltc_polygon_rare(const float* __restrict__ ltc2, V3 L0, V3 L1, V3 L2, V3 L3, bool behind,
+                                                            bool two_sided) {
+    return ltc_polygon(ltc2, L0, L1, L2, L3, behind, two_sided);
+}
+
+// ---- the same tail for the two calls of AreaLight::calculateColor at once (AreaLight.hpp:638,642).
+// _evaluateLTC runs twice per shaded point on different matrices and the same instruction sequence, so the
+// two evaluations ride in the halves of packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32
+// issue at the rate of their scalar forms): component 0 = the identity call, component 1 = the Minv call.
+// Every operation rounds as in the scalar code above; what cannot be packed (reciprocal and square-root
+// estimates, compares, selects) is done per component.
+typedef float F2 __attribute__((ext_vector_type(2)));
+typedef uint32_t U2 __attribute__((ext_vector_type(2)));
+struct P3 { // a pair of vectors, component-wise
+    F2 x, y, z;
+};
+DI F2 splat2(float a) { return F2{a, a}; }
+DI F2 fma2(F2 a, F2 b, F2 c) { return __builtin_elementwise_fma(a, b, c); }
+DI P3 operator+(P3 a, P3 b) { return P3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+DI P3 operator*(P3 a, F2 s) { return P3{a.x * s, a.y * s, a.z * s}; }
+DI F2 dot3(P3 a, P3 b) {
+    F2 r = splat2(0.0f) + a.x * b.x;
+    r = r + a.y * b.y;
+    r = r + a.z * b.z;
+    return r;
+}
+DI F2 dot3(P3 a, V3 b) {
+    F2 r = splat2(0.0f) + a.x * b.x;
+    r = r + a.y * b.y;
+    r = r + a.z * b.z;
+    return r;
+}
+DI P3 cross3(P3 a, P3 b) { return P3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+DI V3 half3(P3 a, int k) { return V3{a.x[k], a.y[k], a.z[k]}; }
+DI F2 rcp_nr(F2 x) { // rcp_nr of both components
+    F2 r = F2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+    F2 e = fma2(-x, r, splat2(1.0f));
+    r = fma2(e, r, r);
+    e = fma2(-x, r, splat2(1.0f));
+    r = fma2(e, r, r);
+    return r;
+}
+DI F2 sqrt_nr(F2 x) { // sqrt_nr of both components
+    F2 s = F2{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+    const U2 sb = __builtin_bit_cast(U2, s);
+    const F2 s_dn = __builtin_bit_cast(F2, sb - 1u), s_up = __builtin_bit_cast(F2, sb + 1u);
+    const F2 r_dn = fma2(-s_dn, s, x), r_up = fma2(-s_up, s, x);
+    s.x = (r_dn.x <= 0.0f) ? s_dn.x : s.x;
+    s.y = (r_dn.y <= 0.0f) ? s_dn.y : s.y;
+    s.x = (r_up.x > 0.0f) ? s_up.x : s.x;
+    s.y = (r_up.y > 0.0f) ? s_up.y : s.y;
+    return s;
+}
+// a / b, correctly rounded, for normal operands whose quotient is normal too (here a in [0.85, 1.4], b in
+// [3.4, 8.6]): with the correctly rounded reciprocal y, q = a*y refined once is within half an ulp and a bit, and
+// the second residual step then rounds to the nearest (Markstein's division theorem) -- the value the IEEE
+// division of the scalar code returns.
+DI F2 div_nr(F2 a, F2 b) {
+    const F2 y = rcp_nr(b);
+    F2 q = a * y;
+    F2 r = fma2(-b, q, a);
+    q = fma2(r, y, q);
+    r = fma2(-b, q, a);
+    return fma2(r, y, q);
+}
+// integrate_edge_vec for a pair of unit-vector pairs (|x| <= 1 + a few ulp)
+DI P3 integrate_edge_vec(P3 v1, P3 v2) {
+    const F2 x = dot3(v1, v2);
+    const F2 y = F2{__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
+    const F2 a = splat2(0.8543985f) + (splat2(0.4965155f) + splat2(0.0145206f) * y) * y;
+    const F2 b = splat2(3.4175940f) + (splat2(4.1616724f) + y) * y;
+    const F2 v = div_nr(a, b);
+    const F2 om = splat2(1.0f) - x * x;
+    const F2 m = F2{max_std(om.x, kEps), max_std(om.y, kEps)}; // in [1e-4, 1]
+    const F2 alt = splat2(0.5f) * rcp_nr(sqrt_nr(m)) - v;
+    const F2 ts = F2{(x.x > 0.0f) ? v.x : alt.x, (x.y > 0.0f) ? v.y : alt.y};
+    return cross3(v1, v2) * ts;
+}
+// Both ltc_polygon calls of one shaded point: L*.x/y/z[0] are the corners under the identity matrix, [1] under
+// Minv.  Returns false, and leaves the sums alone, when some corner does not take the fast path of
+// ray_dir/normalize3 (shorter than 1e-4, huge, or NaN): the caller then evaluates the scalar form.
+DI bool ltc_polygon_pair(const float* __restrict__ ltc2, P3 L0, P3 L1, P3 L2, P3 L3, bool behind, bool two_sided, float& sum0,
+                         float& sum1) {
+    const F2 q0 = dot3(L0, L0), q1 = dot3(L1, L1), q2 = dot3(L2, L2), q3 = dot3(L3, L3);
+    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fminf(q0.x, q0.y), __builtin_fminf(q1.x, q1.y)),
+                                     __builtin_fminf(__builtin_fminf(q2.x, q2.y), __builtin_fminf(q3.x, q3.y)));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(q0.x, q0.y), __builtin_fmaxf(q1.x, q1.y)),
+                                     __builtin_fmaxf(__builtin_fmaxf(q2.x, q2.y), __builtin_fmaxf(q3.x, q3.y)));
+    const bool ordered = q0.x == q0.x && q0.y == q0.y && q1.x == q1.x && q1.y == q1.y && q2.x == q2.x && q2.y == q2.y &&
+                         q3.x == q3.x && q3.y == q3.y;
+    if (!(ordered && lo >= kEpsSq && hi <= 0x1p80f)) return false;
+    // normalize3: v * (1/len) with 1/len == 1/sqrt(len^2) (see normalize3_len)
+    L0 = L0 * rcp_nr(sqrt_nr(q0));
+    L1 = L1 * rcp_nr(sqrt_nr(q1));
+    L2 = L2 * rcp_nr(sqrt_nr(q2));
+    L3 = L3 * rcp_nr(sqrt_nr(q3));
+    P3 vsum = P3{splat2(0.0f), splat2(0.0f), splat2(0.0f)};
+    vsum = vsum + integrate_edge_vec(L0, L1);
+    vsum = vsum + integrate_edge_vec(L1, L2);
+    vsum = vsum + integrate_edge_vec(L2, L3);
+    vsum = vsum + integrate_edge_vec(L3, L0);
+    const F2 lsq = dot3(vsum, vsum);
+    const float LUT_SCALE = 63.0f / 64.0f, LUT_BIAS = 0.5f / 64.0f; // AreaLight.hpp:47-49
+    float out[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float len = length_from_sq(lsq[k]);
+        float z = !eps_equal(len, 0.0f, kEps) ? vsum.z[k] / len : 0.0f;
+        if (behind) z = -z;
+        const float ux = (z * 0.5f + 0.5f) * LUT_SCALE + LUT_BIAS;
+        const float uy = len * LUT_SCALE + LUT_BIAS;
+        const uint32_t tx = ltc_texel(ux), ty = ltc_texel(uy);
+        const float scale = (tx < 64u && ty < 64u) ? ltc2[(ty * 64u + tx) * 4u + 3u] : 0.0f;
+        float sum = len * scale;
+        if (!behind && !two_sided) sum = 0.0f;
+        out[k] = sum;
+    }
+    sum0 = out[0];
+    sum1 = out[1];
+    return true;
 }
 
 // AreaLight::_clipQuadToHorizon + the clipped branch of _evaluateLTC (AreaLight.hpp:104-214,298-334) on the four

@@ -677,7 +677,9 @@ __global__ void __launch_bounds__(64) scatter_kernel(uint32_t nx, uint32_t ny, u
 }
 
 // Exhaustive check of the fast correctly-rounded helpers against the IEEE results over all 2^32 bit
-// patterns: rcp_exact vs 1.0f/x everywhere; rcp_nr vs 1.0f/x and sqrt_nr vs sqrtf on [2^-100, 2^100].
+// patterns: rcp_exact vs 1.0f/x everywhere; rcp_nr vs 1.0f/x and sqrt_nr vs sqrtf on [2^-100, 2^100]; there
+// also the identity normalize3 rests on, 1/(1/(1/x)) == 1/x; and div_nr against the IEEE quotient for every
+// argument integrate_edge_vec can hand it (the two polynomials of y = |x| in [0, 1.00001]).
 __global__ void __launch_bounds__(256) selftest_rcp_kernel(unsigned long long* __restrict__ mismatches,
                                                            uint32_t* __restrict__ first_bad) {
     unsigned long long bad = 0;
@@ -691,6 +693,13 @@ __global__ void __launch_bounds__(256) selftest_rcp_kernel(unsigned long long* _
         if (ax >= 0x1p-100f && ax <= 0x1p100f) {
             same = same && (__float_as_uint(rcp_nr(x)) == __float_as_uint(q));
             if (x > 0.0f) same = same && (__float_as_uint(sqrt_nr(x)) == __float_as_uint(__builtin_sqrtf(x)));
+            same = same && (__float_as_uint(1.0f / (1.0f / q)) == __float_as_uint(q));
+        }
+        if (x >= 0.0f && x <= 1.00001f) {
+            const float pa = 0.8543985f + (0.4965155f + 0.0145206f * x) * x;
+            const float pb = 3.4175940f + (4.1616724f + x) * x;
+            const F2 dq = div_nr(F2{pa, pa}, F2{pb, pb});
+            same = same && (__float_as_uint(dq.x) == __float_as_uint(pa / pb)) && (__float_as_uint(dq.y) == __float_as_uint(pa / pb));
         }
         if (!same) {
             ++bad;

@@ -58,7 +58,7 @@ struct WfWorkspace {
     uint32_t* slot_count = nullptr; // [n_lp]
     float* px_acc = nullptr;        // [3][n_lp] float4: colour of the running color() call, pixel accumulator, first corner of the running AA task
     uint32_t* aa_verdict = nullptr; // [n_lp]: the sum kernel's verdict on a finished level >= 2 AA task
-    uint32_t* work = nullptr;       // [WF_WORK_PLANES][cap_work]
+    uint32_t* work = nullptr;       // shade records: cap_work x WF_WORK_PLANES words, in three arrays of 16-byte groups
     uint32_t* shadow_cnt = nullptr; // [n_lights][cap_work]
     uint32_t* queue = nullptr;      // [3][qcap]
     uint32_t* jump_dev = nullptr;   // two generator jump tables
@@ -86,7 +86,7 @@ struct WfWorkspace {
     double kernel_ms[WF_KERNEL_COUNT] = {0}; // accumulated since the last reset
     uint64_t kernel_launches[WF_KERNEL_COUNT] = {0};
 };
-constexpr uint32_t WF_STATE_PLANES = 49, WF_FRAME_PLANES = 19, WF_WORK_PLANES = 21;
+constexpr uint32_t WF_STATE_PLANES = 49, WF_FRAME_PLANES = 19, WF_WORK_PLANES = 24; // words per shade record: six 16-byte groups (crt_wavefront.hip)
 constexpr uint32_t WF_CTR_RING = 4;
 enum WfCounter : uint32_t {
     WF_CTR_WORK = 0,    // record indices handed out this round

@@ -72,10 +72,6 @@ DI V4 area_light_shade(const float* __restrict__ ltc, const DevLight CRT_CONST* 
     bool behind = dot3(w0, ld3c(L->light_normal)) < 0.0f;
     bool two_sided = L->two_sided != 0u;
     const bool clip = CLIP && L->horizon_clip != 0u; // wave-uniform: the clipped branch of _evaluateLTC (AreaLight.hpp:298-334)
-    // identity * transpose(T1,T2,N): rows T1, T2, N
-    const V3 d0 = mk3(dot3(T1, w0), dot3(T2, w0), dot3(N, w0)), d1 = mk3(dot3(T1, w1), dot3(T2, w1), dot3(N, w1));
-    const V3 d2 = mk3(dot3(T1, w2), dot3(T2, w2), dot3(N, w2)), d3 = mk3(dot3(T1, w3), dot3(T2, w3), dot3(N, w3));
-    float dsum = clip ? ltc_polygon_clipped(d0, d1, d2, d3, two_sided) : ltc_polygon(ltc2, d0, d1, d2, d3, behind, two_sided);
     // Minv(t1) * transpose(T1,T2,N): row0 = t1.x*T1 + t1.z*N, row1 = T2, row2 = t1.y*T1 + t1.w*N
     // (mat3 product accumulates 0 + a*T1 + 0*T2 + c*N per entry, mat.hpp:1481-1492)
     V3 r0 = mk3((0.0f + t1.x * T1.x) + 0.0f * T2.x + t1.z * N.x, (0.0f + t1.x * T1.y) + 0.0f * T2.y + t1.z * N.y,
@@ -84,9 +80,29 @@ DI V4 area_light_shade(const float* __restrict__ ltc, const DevLight CRT_CONST* 
                 (0.0f + 0.0f * T1.z) + 1.0f * T2.z + 0.0f * N.z);
     V3 r2 = mk3((0.0f + t1.y * T1.x) + 0.0f * T2.x + t1.w * N.x, (0.0f + t1.y * T1.y) + 0.0f * T2.y + t1.w * N.y,
                 (0.0f + t1.y * T1.z) + 0.0f * T2.z + t1.w * N.z);
-    const V3 s0 = mk3(dot3(r0, w0), dot3(r1, w0), dot3(r2, w0)), s1 = mk3(dot3(r0, w1), dot3(r1, w1), dot3(r2, w1));
-    const V3 s2 = mk3(dot3(r0, w2), dot3(r1, w2), dot3(r2, w2)), s3 = mk3(dot3(r0, w3), dot3(r1, w3), dot3(r2, w3));
-    float ssum = clip ? ltc_polygon_clipped(s0, s1, s2, s3, two_sided) : ltc_polygon(ltc2, s0, s1, s2, s3, behind, two_sided);
+    // Both evaluations side by side: rows (T1, T2, N) of identity * transpose(T1,T2,N) in component 0, rows
+    // (r0, r1, r2) in component 1; corner k under both matrices is (row0 . wk, row1 . wk, row2 . wk).
+    const P3 row0 = P3{F2{T1.x, r0.x}, F2{T1.y, r0.y}, F2{T1.z, r0.z}};
+    const P3 row1 = P3{F2{T2.x, r1.x}, F2{T2.y, r1.y}, F2{T2.z, r1.z}};
+    const P3 row2 = P3{F2{N.x, r2.x}, F2{N.y, r2.y}, F2{N.z, r2.z}};
+    const P3 c0 = P3{dot3(row0, w0), dot3(row1, w0), dot3(row2, w0)}, c1 = P3{dot3(row0, w1), dot3(row1, w1), dot3(row2, w1)};
+    const P3 c2 = P3{dot3(row0, w2), dot3(row1, w2), dot3(row2, w2)}, c3 = P3{dot3(row0, w3), dot3(row1, w3), dot3(row2, w3)};
+    float dsum = 0.0f, ssum = 0.0f;
+#ifdef CRT_SHADE_SCALAR // measuring aid: both evaluations through the scalar form, inlined
+    const bool paired = false;
+#define ltc_polygon_rare ltc_polygon
+#else
+    const bool paired = !clip && ltc_polygon_pair(ltc2, c0, c1, c2, c3, behind, two_sided, dsum, ssum);
+#endif
+    if (!paired) {
+        const V3 d0 = half3(c0, 0), d1 = half3(c1, 0), d2 = half3(c2, 0), d3 = half3(c3, 0);
+        const V3 s0 = half3(c0, 1), s1 = half3(c1, 1), s2 = half3(c2, 1), s3 = half3(c3, 1);
+        dsum = clip ? ltc_polygon_clipped(d0, d1, d2, d3, two_sided) : ltc_polygon_rare(ltc2, d0, d1, d2, d3, behind, two_sided);
+        ssum = clip ? ltc_polygon_clipped(s0, s1, s2, s3, two_sided) : ltc_polygon_rare(ltc2, s0, s1, s2, s3, behind, two_sided);
+    }
+#ifdef CRT_SHADE_SCALAR
+#undef ltc_polygon_rare
+#endif
     V3 diffuse = (lcol * mk3(dsum, dsum, dsum)) * dcol;
     V3 spec = mk3(ssum, ssum, ssum) * (scol * t2.x + (mk3(1.0f, 1.0f, 1.0f) - scol) * t2.y);
     V3 specular = lcol * spec;

@@ -64,8 +64,14 @@ enum : uint32_t {
 };
 // frame planes
 enum : uint32_t { FR_P = 0, FR_N = 3, FR_ATT = 6, FR_RNG = 10, FR_GEOM = 16, FR_REMAINING = 17, FR_CHILD_DEPTH = 18 };
-// work planes
-enum : uint32_t { WK_P = 0, WK_N = 3, WK_V = 6, WK_ATT = 9, WK_GEOM = 13, WK_RNG = 14, WK_SLOT = 20 };
+// Shade records: three arrays of 16-byte groups behind WfArgs::work, indexed by record (cap_work records each), so
+// that a wave's consecutive records are one contiguous run per array and every access is a 16-byte one:
+//   point  [wi]           {P.x, P.y, P.z, primitive | ordinal << 8}           filter, resolve, shade
+//   surface[3 wi + 0..2]  {N.x, N.y, N.z, result slot} {view.x, view.y, view.z, att.w} {att.x, att.y, att.z, -}   shade
+//   gen    [2 wi + 0..1]  {v0, v1, v2, v3} {v4, d, -, -}                       filter (the records it samples)
+// (Word planes, one per field, had every kernel gather 256-byte pieces from up to 21 streams 650 MB apart: the shade
+// kernel ran at 2.5 TB/s whatever its arithmetic.)
+static_assert(WF_WORK_PLANES == 24, "1 + 3 + 2 groups of four words per record");
 
 struct WfArgs {
     RenderArgs r;
@@ -91,6 +97,18 @@ struct WfArgs {
 
 DI float u2f(uint32_t x) { return __uint_as_float(x); }
 DI uint32_t f2u(float x) { return __float_as_uint(x); }
+// Result slot k of pixel slot lp (tags and contributions).  Unit-major: the quota rows of one 64-pixel unit lie
+// together, a row being the unit's 64 lanes, so what a wave of the trace, shade or sum kernel touches at a time is
+// a few neighbouring kilobytes instead of pieces one whole image apart.
+DI size_t slot_at(const WfArgs& w, uint32_t k, size_t lp) { return ((lp >> 6) * w.quota + k) * 64u + (lp & 63u); }
+DI size_t slot_pixel(const WfArgs& w, size_t slot) { return (slot / ((size_t)w.quota * 64u)) * 64u + (slot & 63u); }
+DI uint4* rec_point(const WfArgs& w) { return reinterpret_cast<uint4*>(w.work); }
+DI uint4* rec_surface(const WfArgs& w) { return reinterpret_cast<uint4*>(w.work) + (size_t)w.cap_work; }
+DI uint4* rec_gen(const WfArgs& w) { return reinterpret_cast<uint4*>(w.work) + (size_t)w.cap_work * 4u; }
+DI Rng rec_load_gen(const WfArgs& w, uint32_t wi) {
+    const uint4 g0 = rec_gen(w)[2u * (size_t)wi], g1 = rec_gen(w)[2u * (size_t)wi + 1u];
+    return Rng{g0.x, g0.y, g0.z, g0.w, g1.x, g1.y};
+}
 
 // ------------------------------------------------------------------------- shadow-ray classification
 // Constants of AreaLight::_randomPoint (AreaLight.hpp:340-375) in scalar registers.
@@ -989,29 +1007,14 @@ DI void store_record(const WfArgs& w, uint32_t wi, V3 P, V3 N, V3 view, V4 att, 
                      uint32_t ordinal = 0u) {
     PROF_LANES(11);
     if (wi < w.cap_work) {
-        uint32_t* r = w.work + wi;
-        const size_t cw = w.cap_work;
-        r[(WK_P + 0) * cw] = f2u(P.x);
-        r[(WK_P + 1) * cw] = f2u(P.y);
-        r[(WK_P + 2) * cw] = f2u(P.z);
-        r[(WK_N + 0) * cw] = f2u(N.x);
-        r[(WK_N + 1) * cw] = f2u(N.y);
-        r[(WK_N + 2) * cw] = f2u(N.z);
-        r[(WK_V + 0) * cw] = f2u(view.x);
-        r[(WK_V + 1) * cw] = f2u(view.y);
-        r[(WK_V + 2) * cw] = f2u(view.z);
-        r[(WK_ATT + 0) * cw] = f2u(att.x);
-        r[(WK_ATT + 1) * cw] = f2u(att.y);
-        r[(WK_ATT + 2) * cw] = f2u(att.z);
-        r[(WK_ATT + 3) * cw] = f2u(att.w);
-        r[WK_GEOM * cw] = geom | (ordinal << 8);
-        r[(WK_RNG + 0) * cw] = rng.v0;
-        r[(WK_RNG + 1) * cw] = rng.v1;
-        r[(WK_RNG + 2) * cw] = rng.v2;
-        r[(WK_RNG + 3) * cw] = rng.v3;
-        r[(WK_RNG + 4) * cw] = rng.v4;
-        r[(WK_RNG + 5) * cw] = rng.d;
-        r[WK_SLOT * cw] = slot;
+        rec_point(w)[wi] = make_uint4(f2u(P.x), f2u(P.y), f2u(P.z), geom | (ordinal << 8));
+        uint4* sf = rec_surface(w) + 3u * (size_t)wi;
+        sf[0] = make_uint4(f2u(N.x), f2u(N.y), f2u(N.z), slot);
+        sf[1] = make_uint4(f2u(view.x), f2u(view.y), f2u(view.z), f2u(att.w));
+        sf[2] = make_uint4(f2u(att.x), f2u(att.y), f2u(att.z), 0u);
+        uint4* gn = rec_gen(w) + 2u * (size_t)wi;
+        gn[0] = make_uint4(rng.v0, rng.v1, rng.v2, rng.v3);
+        gn[1] = make_uint4(rng.v4, rng.d, 0u, 0u);
     } else {
         w.ctrs[WF_CTR_ERROR] = 1u;
     }
@@ -1296,7 +1299,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                     }
                     if (!task_active) {
                         // render() epilogue (main.cu:339-346) happens in the sum kernel
-                        w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)TAG_END_PIXEL;
+                        w.tags[slot_at(w, cnt, lp)] = (uint8_t)TAG_END_PIXEL;
                         ++cnt;
                         done = true;
                     } else {
@@ -1339,7 +1342,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                     }
                 } else if (nframes == 0) {
                     // color() returned (main.cu:225): the sum kernel folds it into the pixel
-                    w.tags[(size_t)cnt * n_lp + lp] = (uint8_t)(TAG_END_CALL | (t_level << 2) | (t_corner << 5));
+                    w.tags[slot_at(w, cnt, lp)] = (uint8_t)(TAG_END_CALL | (t_level << 2) | (t_corner << 5));
                     ++cnt;
                     color_active = false;
                     if (t_level == 0u || ++t_corner == 4u) {
@@ -1416,7 +1419,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                     if (what == POP_MISS) {
                         // final_color += attenuation * Color::black() (main.cu:149-151)
                         const V4 c = att * V4{0.0f, 0.0f, 0.0f, 1.0f};
-                        w.contrib[(size_t)cnt * n_lp + lp] = make_float4(c.x, c.y, c.z, c.w);
+                        w.contrib[slot_at(w, cnt, lp)] = make_float4(c.x, c.y, c.z, c.w);
                         ++cnt;
                     } else if (what == POP_DIFFUSE) {
                         emit = true;
@@ -1443,11 +1446,11 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
             if (rm != 0) my_wi = reserve_records(w, wc, rm, lane);
             if (emit) {
                 PROF_LANES(10);
-                if (dark) w.contrib[(size_t)cnt * n_lp + lp] = dark_c;
+                if (dark) w.contrib[slot_at(w, cnt, lp)] = dark_c;
 #ifdef CRT_ABLATE_STORE
-                else if (n_P.x == 1234.5f) store_record(w, my_wi, n_P, n_N, n_view, n_att, n_geom, rng, (uint32_t)((size_t)cnt * n_lp + lp));
+                else if (n_P.x == 1234.5f) store_record(w, my_wi, n_P, n_N, n_view, n_att, n_geom, rng, (uint32_t)slot_at(w, cnt, lp));
 #else
-                else store_record(w, my_wi, n_P, n_N, n_view, n_att, n_geom, rng, (uint32_t)((size_t)cnt * n_lp + lp));
+                else store_record(w, my_wi, n_P, n_N, n_view, n_att, n_geom, rng, (uint32_t)slot_at(w, cnt, lp));
 #endif
                 ++cnt;
                 ++cnt_shade;
@@ -1575,13 +1578,13 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                 PROF_MARK(6);
                 if (outcome == 1u) {
                     const V4 c = r_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
-                    w.contrib[(size_t)slot_k * n_lp + o_lp] = make_float4(c.x, c.y, c.z, c.w);
+                    w.contrib[slot_at(w, slot_k, o_lp)] = make_float4(c.x, c.y, c.z, c.w);
                 }
-                if (dark) w.contrib[(size_t)slot_k * n_lp + o_lp] = dark_c;
+                if (dark) w.contrib[slot_at(w, slot_k, o_lp)] = dark_c;
                 if (m_store != 0) {
                     const uint32_t my_wi = reserve_records(w, wc, m_store, lane);
                     if (outcome == 2u && !dark)
-                        store_record(w, my_wi, c_P, c_N, c_view, r_att, c_geom, o_rng, (uint32_t)((size_t)slot_k * n_lp + o_lp),
+                        store_record(w, my_wi, c_P, c_N, c_view, r_att, c_geom, o_rng, (uint32_t)slot_at(w, slot_k, o_lp),
                                      lane_rank(m_rec));
                 }
                 // ---- hand the results back to the owner
@@ -1613,7 +1616,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
     // ---- the unused tail of the last chunk holds no record
     if (wc.have)
         for (uint32_t k = wc.used + lane; k < kWorkChunk; k += 64u)
-            if (wc.base + k < w.cap_work) w.work[(size_t)WK_GEOM * w.cap_work + wc.base + k] = kNoRecord;
+            if (wc.base + k < w.cap_work) rec_point(w)[wc.base + k].w = kNoRecord;
 
     // ---- park the traversal
     if (own) w.slot_count[lp] = cnt;
@@ -1725,23 +1728,17 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
         for (uint32_t base = blockIdx.x * 64u; w_begin < w_end && base < w_end - w_begin; base += gridDim.x * 64u) {
             const uint32_t wi = w_begin + base + lane;
             const uint32_t wr = wi < w_end ? wi : w_begin;
-            const uint32_t gword = w.work[(size_t)WK_GEOM * cw + wr];
+            const uint4 pt = rec_point(w)[wr];
+            const uint32_t gword = pt.w;
             const bool act = wi < w_end && gword != kNoRecord;
-            const uint32_t* r = w.work + wr;
-            const V3 P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
+            const V3 P = mk3(u2f(pt.x), u2f(pt.y), u2f(pt.z));
             const uint32_t c = record_light_class(sc, li, lf, P);
             if (act && c != 0u) w.shadow_cnt[(size_t)li * cw + wi] = (c == 2u) ? S : 0u;
             const bool queue = act && c == 0u;
             const uint64_t qm = __ballot(queue);
             if (qm != 0) {
                 if (queue) {
-                    Rng rng;
-                    rng.v0 = r[(WK_RNG + 0) * cw];
-                    rng.v1 = r[(WK_RNG + 1) * cw];
-                    rng.v2 = r[(WK_RNG + 2) * cw];
-                    rng.v3 = r[(WK_RNG + 3) * cw];
-                    rng.v4 = r[(WK_RNG + 4) * cw];
-                    rng.d = r[(WK_RNG + 5) * cw];
+                    Rng rng = rec_load_gen(w, wr);
                     for (uint32_t k = 0; k < draws_before; ++k) rng_step(rng);
                     const uint32_t slot = rqn + lane_rank(qm);
                     rq[0][slot] = wi;
@@ -1774,24 +1771,17 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
 __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin, uint32_t w_end) {
     ScenePtr sc = (ScenePtr)w.r.scene;
     const uint32_t lane = threadIdx.x;
-    const size_t cw = w.cap_work;
     const uint32_t n_lights = sc->n_lights;
     unsigned long long decided = 0, bad = 0;
     if (w_end == kFromCounter) w_end = min(w.ctrs[WF_CTR_WORK], w.cap_work);
     for (uint32_t base = blockIdx.x * 64u; w_begin < w_end && base < w_end - w_begin; base += gridDim.x * 64u) {
         const uint32_t wi = w_begin + base + lane;
         const uint32_t wr = wi < w_end ? wi : w_begin;
-        const uint32_t gword = w.work[(size_t)WK_GEOM * cw + wr];
+        const uint4 pt = rec_point(w)[wr];
+        const uint32_t gword = pt.w;
         const bool act = wi < w_end && gword != kNoRecord;
-        const uint32_t* r = w.work + wr;
-        const V3 P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
-        Rng rng;
-        rng.v0 = r[(WK_RNG + 0) * cw];
-        rng.v1 = r[(WK_RNG + 1) * cw];
-        rng.v2 = r[(WK_RNG + 2) * cw];
-        rng.v3 = r[(WK_RNG + 3) * cw];
-        rng.v4 = r[(WK_RNG + 4) * cw];
-        rng.d = r[(WK_RNG + 5) * cw];
+        const V3 P = mk3(u2f(pt.x), u2f(pt.y), u2f(pt.z));
+        Rng rng = rec_load_gen(w, wr);
         if (act) ordinal_jump(rng, (gword >> 8) & 63u, w);
         for (uint32_t li = 0; li < n_lights; ++li) {
             const DevLight CRT_CONST* L = &sc->lights[li];
@@ -1814,7 +1804,7 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
                 }
 #ifdef CRT_SHADE_TRACE
                 if (act) {
-                    const uint32_t lp_ = r[WK_SLOT * cw] % w.n_lp;
+                    const uint32_t lp_ = (uint32_t)slot_pixel(w, rec_surface(w)[3u * (size_t)wr].w);
                     const PixelMap pm_ = map_pixel(w.r, lp_ / 64u, lp_ % 64u);
                     if (pm_.valid && pm_.j * w.r.nx + pm_.i == (uint32_t)(CRT_SHADE_TRACE)) {
                         V3 o_, d_;
@@ -1916,8 +1906,8 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
         if (act) {
             u = u2f(w.queue[(size_t)w.qcap + idx]);
             v = u2f(w.queue[2 * (size_t)w.qcap + idx]);
-            const uint32_t* r = w.work + (key & 0x0fffffffu);
-            P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
+            const uint4 pt = rec_point(w)[key & 0x0fffffffu];
+            P = mk3(u2f(pt.x), u2f(pt.y), u2f(pt.z));
         } else {
             key = 0u;
         }
@@ -1971,30 +1961,40 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
 }
 
 // ---------------------------------------------------------------------------------------- shade
-// One block per 64 records; the grid covers the workspace's capacity and blocks beyond the round's record
-// count (read from the device counter) leave at once.
+// One lane per record, workgroups of 256 = one chunk of record indices (kWorkChunk); the grid covers what the launch
+// can produce at most and workgroups beyond the round's record count (read from the device counter) leave at once.
+// The kernel is bound by its scattered 16-byte result stores, not by arithmetic (with the LTC evaluation compiled
+// out it takes as long); measured per workgroup size 64 / 128 / 256 / 512 / 1024: 3.4 / 3.2 / 3.0 / 3.2 / 3.5 ms
+// per 720x720 gl_iter 1 frame, and several groups per wave in a loop are no faster than one.
 // CLIP: some light takes the horizon-clipping LTC branch (crt_light::horizonClip).
 template <bool CLIP>
 DI void shade_record(const WfArgs& w, ScenePtr sc, uint32_t wi);
+#ifndef CRT_SHADE_WAVES
+#define CRT_SHADE_WAVES 4
+#endif
+#ifndef CRT_SHADE_BLOCK
+#define CRT_SHADE_BLOCK 256
+#endif
 template <bool CLIP>
-__global__ void __launch_bounds__(64, 4) wf_shade_kernel(WfArgs w) {
-    const uint32_t wi = blockIdx.x * 64u + threadIdx.x;
+__global__ void __launch_bounds__(CRT_SHADE_BLOCK, CRT_SHADE_WAVES) wf_shade_kernel(WfArgs w) {
+    const uint32_t wi = blockIdx.x * (uint32_t)CRT_SHADE_BLOCK + threadIdx.x;
     if (wi >= min(w.ctrs[WF_CTR_WORK], w.cap_work)) return;
     shade_record<CLIP>(w, (ScenePtr)w.r.scene, wi);
 }
 template <bool CLIP>
 DI void shade_record(const WfArgs& w, ScenePtr sc, uint32_t wi) {
     const size_t cw = w.cap_work;
-    const uint32_t* r = w.work + wi;
-    const V3 P = mk3(u2f(r[(WK_P + 0) * cw]), u2f(r[(WK_P + 1) * cw]), u2f(r[(WK_P + 2) * cw]));
-    const V3 N = mk3(u2f(r[(WK_N + 0) * cw]), u2f(r[(WK_N + 1) * cw]), u2f(r[(WK_N + 2) * cw]));
-    const V3 view = mk3(u2f(r[(WK_V + 0) * cw]), u2f(r[(WK_V + 1) * cw]), u2f(r[(WK_V + 2) * cw]));
-    const V4 att = V4{u2f(r[(WK_ATT + 0) * cw]), u2f(r[(WK_ATT + 1) * cw]), u2f(r[(WK_ATT + 2) * cw]),
-                      u2f(r[(WK_ATT + 3) * cw])};
-    const uint32_t gword = r[WK_GEOM * cw];
+    const uint4 pt = rec_point(w)[wi];
+    const uint4* sf = rec_surface(w) + 3u * (size_t)wi;
+    const uint4 s0 = sf[0], s1 = sf[1], s2 = sf[2];
+    const V3 P = mk3(u2f(pt.x), u2f(pt.y), u2f(pt.z));
+    const V3 N = mk3(u2f(s0.x), u2f(s0.y), u2f(s0.z));
+    const V3 view = mk3(u2f(s1.x), u2f(s1.y), u2f(s1.z));
+    const V4 att = V4{u2f(s2.x), u2f(s2.y), u2f(s2.z), u2f(s1.w)};
+    const uint32_t gword = pt.w;
     if (gword == kNoRecord) return;
     const uint32_t geom = gword & 0xffu; // bits 8..13: the record's ordinal in a cooperative batch
-    const uint32_t slot = r[WK_SLOT * cw];
+    const uint32_t slot = s0.w;
     const DevGeomShade CRT_CONST* gs = &sc->shade[geom];
     V4 direct = V4{0, 0, 0, 0}; // LightList::calculateColor (LightList.hpp:23-36)
     const uint32_t n_lights = sc->n_lights;
@@ -2011,14 +2011,18 @@ DI void shade_record(const WfArgs& w, ScenePtr sc, uint32_t wi) {
             float visibility = 1.0f - ((float)shadowed / (float)S); // AreaLight.hpp:527
 #ifdef CRT_SHADE_TRACE // build with -DCRT_SHADE_TRACE=<pixel index j*nx+i>: the shadow counts of that pixel's shaded points
             {
-                const uint32_t lp = slot % w.n_lp;
+                const uint32_t lp = (uint32_t)slot_pixel(w, slot);
                 const PixelMap pm = map_pixel(w.r, lp / 64u, lp % 64u);
                 if (pm.valid && pm.j * w.r.nx + pm.i == (uint32_t)(CRT_SHADE_TRACE))
                     printf("gpu: P=(%.9g %.9g %.9g) light at (%.9g %.9g %.9g): %u of %u shadow rays covered\n", P.x, P.y, P.z,
                            L->pos[0], L->pos[1], L->pos[2], shadowed, S);
             }
 #endif
+#ifdef CRT_ABLATE_SHADE // measuring aid: the kernel's loads and store without the LTC arithmetic
+            direct = direct + V4{P.x + N.x + view.x, P.y + N.y + view.y, P.z + N.z + view.z, visibility + gs->ambient[0]};
+#else
             direct = direct + area_light_shade<CLIP>(w.r.ltc, L, gs, P, N, view, visibility);
+#endif
         }
     }
     const V4 c = att * direct; // final_color += attenuation * light (main.cu:195)
@@ -2058,8 +2062,8 @@ __global__ void __launch_bounds__(64) wf_sum_kernel(WfArgs w, uint32_t first) {
 #pragma unroll
             for (uint32_t j = 0; j < kAhead; ++j) {
                 const uint32_t kk = k + j < cnt ? k + j : cnt - 1u;
-                tags[j] = w.tags[(size_t)kk * n_lp + lp];
-                contribs[j] = w.contrib[(size_t)kk * n_lp + lp];
+                tags[j] = w.tags[slot_at(w, kk, lp)];
+                contribs[j] = w.contrib[slot_at(w, kk, lp)];
             }
         }
         uint32_t tag = tags[0];
@@ -2474,8 +2478,9 @@ hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const G
                 WF_TIMED(WF_K_RESOLVE, hipLaunchKernelGGL(wf_resolve_kernel, dim3(g.resolve), dim3(64), 0, stream, w));
             }
         }
-        if (args.horizon_clip) WF_TIMED(WF_K_SHADE, hipLaunchKernelGGL(wf_shade_kernel<true>, dim3(g.shade), dim3(64), 0, stream, w));
-        else WF_TIMED(WF_K_SHADE, hipLaunchKernelGGL(wf_shade_kernel<false>, dim3(g.shade), dim3(64), 0, stream, w));
+        const dim3 sgrid((g.shade * 64u + CRT_SHADE_BLOCK - 1u) / CRT_SHADE_BLOCK), sblock(CRT_SHADE_BLOCK);
+        if (args.horizon_clip) WF_TIMED(WF_K_SHADE, hipLaunchKernelGGL(wf_shade_kernel<true>, sgrid, sblock, 0, stream, w));
+        else WF_TIMED(WF_K_SHADE, hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, stream, w));
         if (args.n_units < 4096u) WF_TIMED(WF_K_SUM, hipLaunchKernelGGL(wf_sum_kernel<true>, dim3(args.n_units), dim3(64), 0, stream, w, first));
         else WF_TIMED(WF_K_SUM, hipLaunchKernelGGL(wf_sum_kernel<false>, dim3(args.n_units), dim3(64), 0, stream, w, first));
         e = hipGetLastError();
