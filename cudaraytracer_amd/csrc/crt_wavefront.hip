@@ -851,6 +851,10 @@ DI void ordinal_jump(Rng& rng, uint32_t k, const WfArgs& w) { // k shaded points
 // waves share the unit: the batches of one wave run back to back, so fewer owners per wave means more
 // of them in flight.
 constexpr uint32_t kCoopSplit = 8;
+constexpr uint32_t kCoopOwners = 64u / kCoopSplit;
+// what the cooperative expansion keeps per owner in LDS while the wave works through the owners' children
+enum : uint32_t { OW_PRE = 0, OW_N, OW_LP, OW_NFRAMES, OW_CNT, OW_REM, OW_RNG, OW_RAY_D = OW_RNG + 6, OW_LANE = OW_RAY_D + 3, OW_SLOTS, OW_RECS, OW_WORDS };
+DI uint64_t lanes_below(uint32_t k) { return k >= 64u ? ~0ull : (1ull << k) - 1ull; }
 
 // Children of the innermost frame leave last-to-first (main.cu:176-191 pushes, :132 pops):
 // get_random_ray_values_in_hemisphere (main.cu:60-74) and the child's attenuation (main.cu:186).
@@ -1162,6 +1166,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
     __shared__ __attribute__((aligned(16))) uint32_t s_jump[2][kJumpWords];
     // one row per primitive of the scene (dynamic, sized by the launch): with the two jump tables the workgroup
     // stays under 32 KB for scenes of up to 49 primitives, so that five workgroups fit a CU's LDS
+    __shared__ uint32_t s_coop[COOP ? kTraceWaves : 1u][COOP ? kCoopOwners * OW_WORDS : 1u];
     extern __shared__ __attribute__((aligned(16))) float s_prim_words[];
     PrimRow* s_prim = reinterpret_cast<PrimRow*>(s_prim_words);
     for (uint32_t k = threadIdx.x; k < 2u * kJumpWords; k += 64u * kTraceWaves)
@@ -1505,103 +1510,167 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
         }
         PROF_MARK(2);
         if (COOP) {
-            // ---- leaf children: one lane per child ray, one owner (pixel) after the other.  Every child
-            // fills at most one result slot, so a batch of n <= quota - cnt children respects the quota.
-            uint64_t cm = __ballot(want_coop);
-            while (cm != 0) {
-                const int owner = __builtin_ctzll(cm);
-                cm &= cm - 1u;
-                const uint32_t o_lp = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)lp, owner);
-                const uint32_t o_nframes = (uint32_t)__builtin_amdgcn_readlane((int)nframes, owner);
-                const uint32_t o_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, owner);
-                Rng o_rng;
-                o_rng.v0 = (uint32_t)__builtin_amdgcn_readlane((int)rng.v0, owner);
-                o_rng.v1 = (uint32_t)__builtin_amdgcn_readlane((int)rng.v1, owner);
-                o_rng.v2 = (uint32_t)__builtin_amdgcn_readlane((int)rng.v2, owner);
-                o_rng.v3 = (uint32_t)__builtin_amdgcn_readlane((int)rng.v3, owner);
-                o_rng.v4 = (uint32_t)__builtin_amdgcn_readlane((int)rng.v4, owner);
-                o_rng.d = (uint32_t)__builtin_amdgcn_readlane((int)rng.d, owner);
-                V3 c_ray_d = mk3(u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(ray_d.x), owner)),
-                                 u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(ray_d.y), owner)),
-                                 u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(ray_d.z), owner)));
-                uint32_t* f = w.frames + ((size_t)(o_nframes - 1u) * WF_FRAME_PLANES) * n_lp + o_lp;
-                const uint32_t rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[FR_REMAINING * n_lp]);
-                const V3 hp = mk3(u2f(f[(FR_P + 0) * n_lp]), u2f(f[(FR_P + 1) * n_lp]), u2f(f[(FR_P + 2) * n_lp]));
-                const V3 hn = mk3(u2f(f[(FR_N + 0) * n_lp]), u2f(f[(FR_N + 1) * n_lp]), u2f(f[(FR_N + 2) * n_lp]));
-                const V4 patt = V4{u2f(f[(FR_ATT + 0) * n_lp]), u2f(f[(FR_ATT + 1) * n_lp]), u2f(f[(FR_ATT + 2) * n_lp]),
-                                   u2f(f[(FR_ATT + 3) * n_lp])};
-                const float* fpr = s_prim[f[FR_GEOM * n_lp]];
-                const V4 pdiff = V4{fpr[12], fpr[13], fpr[14], fpr[15]};
-                uint32_t n = rem < quota - o_cnt ? rem : quota - o_cnt;
-                if (n > kCoopBatch) n = kCoopBatch;
-                const bool act = lane < n;
-                // lane j takes the j-th child to leave the stack: child rem-1-j, drawn as pair rem-1-j
-                const uint32_t child = act ? rem - 1u - lane : 0u;
-                const float r1 = w.draws[(size_t)(2u * child) * n_lp + o_lp];
-                const float r2 = w.draws[(size_t)(2u * child + 1u) * n_lp + o_lp];
-                V3 c_o, c_d;
-                V4 c_att;
-                child_ray(hp, hn, patt, pdiff, r1, r2, inv_ind, c_o, c_d, c_att);
-                uint32_t c_ref = a.ref_iter;
-                PROF_MARK(4);
-                // the child's chain of mirror / glass bounces (main.cu:132-221 with gl_depth 0)
-                uint32_t outcome = 0; // 0 no slot (bounces used up), 1 miss, 2 diffuse hit
-                V3 c_P = mk3(0, 0, 0), c_N = mk3(0, 0, 0), c_view = mk3(0, 0, 0);
-                V4 r_att = V4{0, 0, 0, 0};
-                uint32_t c_geom = 0;
-                bool running = act;
-                while (__any(running)) {
-                    if (running) {
-                        running = false;
-                        if (c_ref != 0u) {
-                            c_view = neg(c_d);
-                            r_att = c_att;
-                            const uint32_t what = pop_ray(sc, s_prim, c_o, c_d, c_att, c_ref, c_ray_d, c_P, c_N, c_geom);
-                            if (what == POP_MISS) outcome = 1u;
-                            else if (what == POP_DIFFUSE) outcome = 2u;
-                            else running = true;
+            // ---- leaf children: one lane per child ray.  The owners (pixels) that want their innermost frame expanded
+            // put up to kCoopBatch children each into one list, in lane order, and the wave works through the list 64
+            // entries at a time, so a batch can hold the children of two or more owners (75 children per owner are
+            // 10 batches for the wave's 8 owners instead of 16).  Every child fills at most one result slot, so
+            // n <= quota - cnt children of an owner respect its quota.
+            const uint64_t cm = __ballot(want_coop);
+            if (cm != 0) {
+                uint32_t* own_tab = s_coop[threadIdx.x >> 6]; // [kCoopOwners][OW_WORDS], this wave's
+                uint32_t my_rem = 0, my_n = 0;
+                if (want_coop) {
+                    my_rem = w.frames[((size_t)(nframes - 1u) * WF_FRAME_PLANES + FR_REMAINING) * n_lp + lp];
+                    my_n = my_rem < quota - cnt ? my_rem : quota - cnt;
+                    if (my_n > kCoopBatch) my_n = kCoopBatch;
+                }
+                uint32_t my_pre = 0, total = 0, n_own = 0; // list position of an owner's first child; list length; owners
+                for (uint64_t m = cm; m != 0; m &= m - 1u) {
+                    const int o = __builtin_ctzll(m);
+                    if (lane == (uint32_t)o) my_pre = total;
+                    total += (uint32_t)__builtin_amdgcn_readlane((int)my_n, o);
+                    ++n_own;
+                }
+                if (want_coop) {
+                    uint32_t* oj = own_tab + lane_rank(cm) * OW_WORDS;
+                    oj[OW_PRE] = my_pre;
+                    oj[OW_N] = my_n;
+                    oj[OW_LP] = (uint32_t)lp;
+                    oj[OW_NFRAMES] = nframes;
+                    oj[OW_CNT] = cnt;
+                    oj[OW_REM] = my_rem;
+                    oj[OW_RNG + 0] = rng.v0;
+                    oj[OW_RNG + 1] = rng.v1;
+                    oj[OW_RNG + 2] = rng.v2;
+                    oj[OW_RNG + 3] = rng.v3;
+                    oj[OW_RNG + 4] = rng.v4;
+                    oj[OW_RNG + 5] = rng.d;
+                    oj[OW_RAY_D + 0] = f2u(ray_d.x);
+                    oj[OW_RAY_D + 1] = f2u(ray_d.y);
+                    oj[OW_RAY_D + 2] = f2u(ray_d.z);
+                    oj[OW_LANE] = lane;
+                    oj[OW_SLOTS] = 0u; // result slots / diffuse hits of this owner in earlier batches of the list
+                    oj[OW_RECS] = 0u;
+                }
+                for (uint32_t b0 = 0; b0 < total; b0 += 64u) {
+                    const uint32_t p = b0 + lane;
+                    const bool act = p < total;
+                    uint32_t j = 0; // the owner whose children cover list position p
+                    for (uint32_t jj = 1; jj < n_own; ++jj)
+                        if (p >= own_tab[jj * OW_WORDS + OW_PRE]) j = jj;
+                    const uint32_t* oj = own_tab + j * OW_WORDS;
+                    const uint32_t o_lp = oj[OW_LP], o_rem = oj[OW_REM];
+                    V3 c_ray_d = mk3(u2f(oj[OW_RAY_D + 0]), u2f(oj[OW_RAY_D + 1]), u2f(oj[OW_RAY_D + 2]));
+                    const uint32_t* f = w.frames + ((size_t)(oj[OW_NFRAMES] - 1u) * WF_FRAME_PLANES) * n_lp + o_lp;
+                    const V3 hp = mk3(u2f(f[(FR_P + 0) * n_lp]), u2f(f[(FR_P + 1) * n_lp]), u2f(f[(FR_P + 2) * n_lp]));
+                    const V3 hn = mk3(u2f(f[(FR_N + 0) * n_lp]), u2f(f[(FR_N + 1) * n_lp]), u2f(f[(FR_N + 2) * n_lp]));
+                    const V4 patt = V4{u2f(f[(FR_ATT + 0) * n_lp]), u2f(f[(FR_ATT + 1) * n_lp]), u2f(f[(FR_ATT + 2) * n_lp]),
+                                       u2f(f[(FR_ATT + 3) * n_lp])};
+                    const float* fpr = s_prim[f[FR_GEOM * n_lp]];
+                    const V4 pdiff = V4{fpr[12], fpr[13], fpr[14], fpr[15]};
+                    // the c-th child of its owner to leave the stack: child rem-1-c, drawn as pair rem-1-c
+                    const uint32_t child = o_rem - 1u - (act ? p - oj[OW_PRE] : 0u);
+                    const float r1 = w.draws[(size_t)(2u * child) * n_lp + o_lp];
+                    const float r2 = w.draws[(size_t)(2u * child + 1u) * n_lp + o_lp];
+                    V3 c_o, c_d;
+                    V4 c_att;
+                    child_ray(hp, hn, patt, pdiff, r1, r2, inv_ind, c_o, c_d, c_att);
+                    uint32_t c_ref = a.ref_iter;
+                    PROF_MARK(4);
+                    // the child's chain of mirror / glass bounces (main.cu:132-221 with gl_depth 0)
+                    uint32_t outcome = 0; // 0 no slot (bounces used up), 1 miss, 2 diffuse hit
+                    V3 c_P = mk3(0, 0, 0), c_N = mk3(0, 0, 0), c_view = mk3(0, 0, 0);
+                    V4 r_att = V4{0, 0, 0, 0};
+                    uint32_t c_geom = 0;
+                    bool running = act;
+                    while (__any(running)) {
+                        if (running) {
+                            running = false;
+                            if (c_ref != 0u) {
+                                c_view = neg(c_d);
+                                r_att = c_att;
+                                const uint32_t what = pop_ray(sc, s_prim, c_o, c_d, c_att, c_ref, c_ray_d, c_P, c_N, c_geom);
+                                if (what == POP_MISS) outcome = 1u;
+                                else if (what == POP_DIFFUSE) outcome = 2u;
+                                else running = true;
+                            }
                         }
                     }
+                    PROF_MARK(5);
+                    // m_rec: the batch's diffuse hits in list order; within an owner that is child order, and each
+                    // moves the owner's generator by one shaded point
+                    const uint64_t m_slot = __ballot(outcome != 0u), m_rec = __ballot(outcome == 2u);
+                    // the lanes of this batch that hold children of the same owner, and those of them below this lane
+                    // (the owner's entry is read again here rather than held in registers through the chains)
+                    const uint32_t o_pre = oj[OW_PRE], o_n = oj[OW_N], o_cnt = oj[OW_CNT];
+                    const uint32_t before_slots = oj[OW_SLOTS], before_recs = oj[OW_RECS];
+                    const uint32_t seg_lo = o_pre > b0 ? o_pre - b0 : 0u;
+                    const uint32_t seg_hi = o_pre + o_n - b0 < 64u ? o_pre + o_n - b0 : 64u;
+                    const uint64_t seg = lanes_below(seg_hi) & ~lanes_below(seg_lo);
+                    const uint64_t below = seg & lanes_below(lane);
+                    const uint32_t slot_k = o_cnt + before_slots + (uint32_t)__popcll(m_slot & below);
+                    const uint32_t ordinal = before_recs + (uint32_t)__popcll(m_rec & below);
+                    float4 dark_c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    const bool dark = outcome == 2u && ambient_only(sc, s_prim, c_P, c_geom, r_att, dark_c);
+                    const uint64_t m_store = __ballot(outcome == 2u && !dark); // those that become records
+                    if (outcome == 1u) {
+                        const V4 c = r_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
+                        w.contrib[slot_at(w, slot_k, o_lp)] = make_float4(c.x, c.y, c.z, c.w);
+                    }
+                    if (dark) w.contrib[slot_at(w, slot_k, o_lp)] = dark_c;
+                    if (m_store != 0) {
+                        // the k-th diffuse hit of an owner keeps the owner's generator state and k
+                        const uint32_t my_wi = reserve_records(w, wc, m_store, lane);
+                        if (outcome == 2u && !dark) {
+                            const Rng o_rng = Rng{oj[OW_RNG + 0], oj[OW_RNG + 1], oj[OW_RNG + 2], oj[OW_RNG + 3], oj[OW_RNG + 4], oj[OW_RNG + 5]};
+                            store_record(w, my_wi, c_P, c_N, c_view, r_att, c_geom, o_rng, (uint32_t)slot_at(w, slot_k, o_lp), ordinal);
+                        }
+                    }
+                    PROF_MARK(6);
+                    // ---- owners whose last child was in this batch get their results; one that goes on into the next
+                    // batch has its counts carried over
+                    for (uint32_t jj = 0; jj < n_own; ++jj) {
+                        const uint32_t* ou = own_tab + jj * OW_WORDS;
+                        const uint32_t pre = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_PRE]);
+                        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_N]);
+                        if (pre + n <= b0 || pre >= b0 + 64u) continue;
+                        const uint32_t lo = pre > b0 ? pre - b0 : 0u, hi = pre + n - b0 < 64u ? pre + n - b0 : 64u;
+                        const uint64_t sg = lanes_below(hi) & ~lanes_below(lo);
+                        const uint32_t slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_SLOTS]) + (uint32_t)__popcll(m_slot & sg);
+                        const uint32_t recs = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RECS]) + (uint32_t)__popcll(m_rec & sg);
+                        if (pre + n > b0 + 64u) {
+                            if (lane == 0u) {
+                                own_tab[jj * OW_WORDS + OW_SLOTS] = slots;
+                                own_tab[jj * OW_WORDS + OW_RECS] = recs;
+                            }
+                            continue;
+                        }
+                        // the owner continues `recs` shaded points further on
+                        Rng nr;
+                        nr.v0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RNG + 0]);
+                        nr.v1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RNG + 1]);
+                        nr.v2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RNG + 2]);
+                        nr.v3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RNG + 3]);
+                        nr.v4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RNG + 4]);
+                        nr.d = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RNG + 5]);
+                        ordinal_jump_wave(nr, recs, w, lane);
+                        // the direction register keeps the last ray that had a usable direction (main.cu:138)
+                        const int last = (int)(pre + n - 1u - b0);
+                        const V3 last_d = mk3(u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.x), last)),
+                                              u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.y), last)),
+                                              u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.z), last)));
+                        if (lane == (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_LANE])) {
+                            cnt += slots;
+                            cnt_shade += recs;
+                            rng = nr;
+                            ray_d = last_d;
+                            on_stack -= n;
+                            if (my_rem == n) --nframes;
+                            else w.frames[((size_t)(nframes - 1u) * WF_FRAME_PLANES + FR_REMAINING) * n_lp + lp] = my_rem - n;
+                        }
+                    }
+                    PROF_MARK(7);
                 }
-                PROF_MARK(5);
-                // m_rec: the batch's diffuse hits in child order (each moves the generator by one shaded point)
-                const uint64_t m_slot = __ballot(outcome != 0u), m_rec = __ballot(outcome == 2u);
-                const uint32_t n_rec = (uint32_t)__popcll(m_rec);
-                const uint32_t slot_k = o_cnt + lane_rank(m_slot);
-                float4 dark_c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                const bool dark = outcome == 2u && ambient_only(sc, s_prim, c_P, c_geom, r_att, dark_c);
-                const uint64_t m_store = __ballot(outcome == 2u && !dark); // those that become records
-                // the k-th diffuse hit's record keeps the owner's generator state and k; the owner continues
-                // n_rec shaded points further on
-                Rng nr = o_rng;
-                ordinal_jump_wave(nr, n_rec, w, lane);
-                PROF_MARK(6);
-                if (outcome == 1u) {
-                    const V4 c = r_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
-                    w.contrib[slot_at(w, slot_k, o_lp)] = make_float4(c.x, c.y, c.z, c.w);
-                }
-                if (dark) w.contrib[slot_at(w, slot_k, o_lp)] = dark_c;
-                if (m_store != 0) {
-                    const uint32_t my_wi = reserve_records(w, wc, m_store, lane);
-                    if (outcome == 2u && !dark)
-                        store_record(w, my_wi, c_P, c_N, c_view, r_att, c_geom, o_rng, (uint32_t)slot_at(w, slot_k, o_lp),
-                                     lane_rank(m_rec));
-                }
-                // ---- hand the results back to the owner
-                // the direction register keeps the last ray that had a usable direction (main.cu:138)
-                const V3 last_d = mk3(u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.x), (int)(n - 1u))),
-                                      u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.y), (int)(n - 1u))),
-                                      u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.z), (int)(n - 1u))));
-                if (lane == (uint32_t)owner) {
-                    cnt += (uint32_t)__popcll(m_slot);
-                    cnt_shade += n_rec;
-                    rng = nr;
-                    ray_d = last_d;
-                    on_stack -= n;
-                    if (rem == n) --nframes;
-                    else f[FR_REMAINING * n_lp] = rem - n;
-                }
-                PROF_MARK(7);
             }
         }
         PROF_MARK(3);
