@@ -805,45 +805,12 @@ DI uint32_t record_light_class(ScenePtr sc, uint32_t li, const LightF& lf, V3 P)
 #define CRT_TRACE_BLOCK_WAVES 4
 #endif
 constexpr uint32_t kTraceWaves = CRT_TRACE_BLOCK_WAVES; // waves per trace workgroup (they share the generator jump tables in LDS)
-// Cooperative expansion handles at most 63 children at a time.  The k-th diffuse hit of a batch starts k
-// shaded points' worth of draws after the batch's first; its record keeps the batch's generator state
-// and k (bits 8..13 of the primitive word), and whoever draws from it (the filter kernel, for the fifth
-// of the records whose samples it has to look at) jumps there with table k-1 of 63 in device memory.
-// The owner continues from the state after all of the batch's hits (ordinal_jump_wave); 63 children
-// keep every ordinal and the hit count within the 63 tables.
+// Cooperative expansion takes at most 63 children of a pixel at a time.  The k-th diffuse hit among them starts k
+// shaded points' worth of draws after the first; its record keeps the pixel's generator state and k (bits 8..13 of
+// the primitive word), and whoever draws from it (the filter kernel, for the fifth of the records whose samples it
+// has to look at) jumps there with table k-1 of 63 in device memory.  The pixel itself continues from the state
+// after all of those hits; 63 children keep every ordinal and the hit count within the 63 tables.
 constexpr uint32_t kCoopBatch = 63, kCoopTables = 63;
-// The same jump for a state and a k that are uniform over the wave, done by the wave: lane e < 40 looks up
-// nibble e of the state, an XOR butterfly adds the forty images up, and every lane ends with the result.
-// One trip to the table instead of forty dependent on one lane's address arithmetic.
-DI void ordinal_jump_wave(Rng& rng, uint32_t k, const WfArgs& w, uint32_t lane) {
-    if (k == 0u || w.jump_n[0] == 0u) return;
-    const uint32_t* tab = w.coop_tabs + (size_t)(k - 1u) * kJumpWords;
-    const uint32_t wd = lane >> 3, nb = lane & 7u;
-    const uint32_t word = wd == 0u ? rng.v0 : wd == 1u ? rng.v1 : wd == 2u ? rng.v2 : wd == 3u ? rng.v3 : rng.v4;
-    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
-    if (lane < 40u) {
-        const uint32_t idx = lane * 16u + ((word >> (4u * nb)) & 15u);
-        const uint4 q = reinterpret_cast<const uint4*>(tab)[idx];
-        o0 = q.x;
-        o1 = q.y;
-        o2 = q.z;
-        o3 = q.w;
-        o4 = tab[4u * kJumpEntries + idx];
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        o0 ^= __shfl_xor(o0, off, 64);
-        o1 ^= __shfl_xor(o1, off, 64);
-        o2 ^= __shfl_xor(o2, off, 64);
-        o3 ^= __shfl_xor(o3, off, 64);
-        o4 ^= __shfl_xor(o4, off, 64);
-    }
-    rng.v0 = o0;
-    rng.v1 = o1;
-    rng.v2 = o2;
-    rng.v3 = o3;
-    rng.v4 = o4;
-    rng.d += k * w.jump_n[0] * 362437u;
-}
 DI void ordinal_jump(Rng& rng, uint32_t k, const WfArgs& w) { // k shaded points ahead; k = 0 for records of the per-pixel walk
     if (k != 0u && w.jump_n[0] != 0u) rng_jump(rng, w.coop_tabs + (size_t)(k - 1u) * kJumpWords, k * w.jump_n[0] * 362437u);
 }
@@ -1167,6 +1134,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
     // one row per primitive of the scene (dynamic, sized by the launch): with the two jump tables the workgroup
     // stays under 32 KB for scenes of up to 49 primitives, so that five workgroups fit a CU's LDS
     __shared__ uint32_t s_coop[COOP ? kTraceWaves : 1u][COOP ? kCoopOwners * OW_WORDS : 1u];
+    __shared__ uint32_t s_coop_acc[COOP ? kTraceWaves : 1u][COOP ? kCoopOwners * 5u : 1u];
     extern __shared__ __attribute__((aligned(16))) float s_prim_words[];
     PrimRow* s_prim = reinterpret_cast<PrimRow*>(s_prim_words);
     for (uint32_t k = threadIdx.x; k < 2u * kJumpWords; k += 64u * kTraceWaves)
@@ -1627,49 +1595,61 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                         }
                     }
                     PROF_MARK(6);
-                    // ---- owners whose last child was in this batch get their results; one that goes on into the next
-                    // batch has its counts carried over
-                    for (uint32_t jj = 0; jj < n_own; ++jj) {
-                        const uint32_t* ou = own_tab + jj * OW_WORDS;
-                        const uint32_t pre = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_PRE]);
-                        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_N]);
-                        if (pre + n <= b0 || pre >= b0 + 64u) continue;
-                        const uint32_t lo = pre > b0 ? pre - b0 : 0u, hi = pre + n - b0 < 64u ? pre + n - b0 : 64u;
-                        const uint64_t sg = lanes_below(hi) & ~lanes_below(lo);
-                        const uint32_t slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_SLOTS]) + (uint32_t)__popcll(m_slot & sg);
-                        const uint32_t recs = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RECS]) + (uint32_t)__popcll(m_rec & sg);
-                        if (pre + n > b0 + 64u) {
-                            if (lane == 0u) {
-                                own_tab[jj * OW_WORDS + OW_SLOTS] = slots;
-                                own_tab[jj * OW_WORDS + OW_RECS] = recs;
-                            }
-                            continue;
-                        }
-                        // the owner continues `recs` shaded points further on
-                        Rng nr;
-                        nr.v0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RNG + 0]);
-                        nr.v1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RNG + 1]);
-                        nr.v2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RNG + 2]);
-                        nr.v3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RNG + 3]);
-                        nr.v4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RNG + 4]);
-                        nr.d = (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_RNG + 5]);
-                        ordinal_jump_wave(nr, recs, w, lane);
-                        // the direction register keeps the last ray that had a usable direction (main.cu:138)
-                        const int last = (int)(pre + n - 1u - b0);
-                        const V3 last_d = mk3(u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.x), last)),
-                                              u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.y), last)),
-                                              u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(c_ray_d.z), last)));
-                        if (lane == (uint32_t)__builtin_amdgcn_readfirstlane((int)ou[OW_LANE])) {
-                            cnt += slots;
-                            cnt_shade += recs;
-                            rng = nr;
-                            ray_d = last_d;
-                            on_stack -= n;
-                            if (my_rem == n) --nframes;
-                            else w.frames[((size_t)(nframes - 1u) * WF_FRAME_PLANES + FR_REMAINING) * n_lp + lp] = my_rem - n;
+                    // ---- the last lane of an owner's run in this batch keeps the owner's counts up to date, and the
+                    // lane of its last child leaves the direction register (main.cu:138: the last ray that had a usable
+                    // direction)
+                    if (act && lane + 1u == seg_hi) {
+                        uint32_t* ow = own_tab + j * OW_WORDS;
+                        ow[OW_SLOTS] = before_slots + (uint32_t)__popcll(m_slot & seg);
+                        ow[OW_RECS] = before_recs + (uint32_t)__popcll(m_rec & seg);
+                        if (p + 1u == o_pre + o_n) {
+                            ow[OW_RAY_D + 0] = f2u(c_ray_d.x);
+                            ow[OW_RAY_D + 1] = f2u(c_ray_d.y);
+                            ow[OW_RAY_D + 2] = f2u(c_ray_d.z);
                         }
                     }
                     PROF_MARK(7);
+                }
+                // ---- every owner continues as many shaded points further on as its children had diffuse hits: the
+                // jumps of all owners at once, one table look-up per (owner, nibble) spread over the lanes, their
+                // images added up in LDS
+                uint32_t* acc = s_coop_acc[threadIdx.x >> 6];
+                if (lane < kCoopOwners * 5u) acc[lane] = 0u;
+                if (w.jump_n[0] != 0u) {
+                    for (uint32_t q = lane; q < n_own * 40u; q += 64u) {
+                        const uint32_t o = q / 40u, e = q - o * 40u; // owner, nibble of its state
+                        const uint32_t* ou = own_tab + o * OW_WORDS;
+                        const uint32_t k = ou[OW_RECS];
+                        if (k != 0u) {
+                            const uint32_t* tab = w.coop_tabs + (size_t)(k - 1u) * kJumpWords;
+                            const uint32_t idx = e * 16u + ((ou[OW_RNG + (e >> 3)] >> (4u * (e & 7u))) & 15u);
+                            const uint4 t4 = reinterpret_cast<const uint4*>(tab)[idx];
+                            atomicXor(&acc[o * 5u + 0u], t4.x);
+                            atomicXor(&acc[o * 5u + 1u], t4.y);
+                            atomicXor(&acc[o * 5u + 2u], t4.z);
+                            atomicXor(&acc[o * 5u + 3u], t4.w);
+                            atomicXor(&acc[o * 5u + 4u], tab[4u * kJumpEntries + idx]);
+                        }
+                    }
+                }
+                if (want_coop) {
+                    const uint32_t o = lane_rank(cm);
+                    const uint32_t* ow = own_tab + o * OW_WORDS;
+                    const uint32_t recs = ow[OW_RECS];
+                    cnt += ow[OW_SLOTS];
+                    cnt_shade += recs;
+                    if (recs != 0u && w.jump_n[0] != 0u) {
+                        rng.v0 = acc[o * 5u + 0u];
+                        rng.v1 = acc[o * 5u + 1u];
+                        rng.v2 = acc[o * 5u + 2u];
+                        rng.v3 = acc[o * 5u + 3u];
+                        rng.v4 = acc[o * 5u + 4u];
+                        rng.d += recs * w.jump_n[0] * 362437u;
+                    }
+                    ray_d = mk3(u2f(ow[OW_RAY_D + 0]), u2f(ow[OW_RAY_D + 1]), u2f(ow[OW_RAY_D + 2]));
+                    on_stack -= my_n;
+                    if (my_rem == my_n) --nframes;
+                    else w.frames[((size_t)(nframes - 1u) * WF_FRAME_PLANES + FR_REMAINING) * n_lp + lp] = my_rem - my_n;
                 }
             }
         }
