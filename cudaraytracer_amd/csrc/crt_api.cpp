@@ -114,16 +114,16 @@ crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
 
 // Share (per mille) of this launch's work units, most expensive first, that go through the cooperative
 // trace kernel.  Measured at 720x720 gl_iter 1 (trace kernel, ms): 64 800 pixels, an eighth of the frame:
-// all cooperative 2.2, none 6.6; 129 600 pixels: 15 % 4.1, none 7.1, all 4.2 (but a slower filter kernel);
-// 259 200 pixels: 6 % 5.1, none 8.0; the full frame: none 9.5, 1 % 9.9.  The environment variable is for such measurements
-// (tools/mix_sweep.sh).
+// all cooperative 1.8, none 6.7; 129 600 pixels: all 3.3, 15-60 % 3.8, 6 % 4.1, none 7.1; 259 200 pixels: 6 % 4.8,
+// 15 % 4.9, all 6.4, none 7.7; the full frame: none 9.0, 3 % 8.9, all 12.4.  The environment variable is for such
+// measurements (tools/mix_sweep.sh).
 uint32_t pick_cooperative(const crt_ctx* ctx, const crt::RenderArgs& a) {
     if (a.gl_iter == 0) return 0u;
     if (ctx->trace_mode == CRT_TRACE_COOPERATIVE) return 1000u;
     if (ctx->trace_mode == CRT_TRACE_PER_PIXEL) return 0u;
     if (const char* env = getenv("CRT_COOP_PERMILLE")) return (uint32_t)atoi(env) > 1000u ? 1000u : (uint32_t)atoi(env);
     const uint64_t pixels = (uint64_t)a.n_units * 64u;
-    return pixels < 100000ull ? 1000u : pixels < 200000ull ? 150u : pixels < 400000ull ? 60u : 0u;
+    return pixels < 200000ull ? 1000u : pixels < 400000ull ? 60u : 0u;
 }
 
 // Runs one launch through the pipeline the context selects.
