@@ -52,7 +52,7 @@ struct WfWorkspace {
     uint32_t* ctrs = nullptr;       // device counters (WF_CTR_*)
     uint32_t* ctrs_host = nullptr;  // pinned mirror: WF_CTR_RING copies, one per round in flight
     uint32_t* state = nullptr;      // [WF_STATE_PLANES][n_lp] traversal state between rounds
-    uint32_t* frames = nullptr;     // [gl_levels][WF_FRAME_PLANES][n_lp]
+    uint32_t* frames = nullptr;     // [gl_levels][WF_FRAME_PLANES / 4][n_lp] groups of four words
     uint8_t* tags = nullptr;        // [quota][n_lp]
     float* contrib = nullptr;       // [quota][n_lp] float4
     uint32_t* slot_count = nullptr; // [n_lp]
@@ -86,7 +86,7 @@ struct WfWorkspace {
     double kernel_ms[WF_KERNEL_COUNT] = {0}; // accumulated since the last reset
     uint64_t kernel_launches[WF_KERNEL_COUNT] = {0};
 };
-constexpr uint32_t WF_STATE_PLANES = 49, WF_FRAME_PLANES = 19, WF_WORK_PLANES = 24; // words per shade record: six 16-byte groups (crt_wavefront.hip)
+constexpr uint32_t WF_STATE_PLANES = 49, WF_FRAME_PLANES = 20, WF_WORK_PLANES = 24; // words per shade record: six 16-byte groups (crt_wavefront.hip)
 constexpr uint32_t WF_CTR_RING = 4;
 enum WfCounter : uint32_t {
     WF_CTR_WORK = 0,    // record indices handed out this round

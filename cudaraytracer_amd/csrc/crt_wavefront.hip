@@ -63,7 +63,16 @@ enum : uint32_t {
     ST_AA = 19,                 // AA task stack: 10 x {cx, cy, level} (aa_color, main.cu:235-242; aa_iter <= 4 bounds it)
 };
 // frame planes
-enum : uint32_t { FR_P = 0, FR_N = 3, FR_ATT = 6, FR_RNG = 10, FR_GEOM = 16, FR_REMAINING = 17, FR_CHILD_DEPTH = 18 };
+// A frame is five 16-byte groups, each an array over the pixel slots (a wave reads or writes 1 KB per group):
+enum : uint32_t {
+    FG_POINT = 0, // {P.x, P.y, P.z, primitive}
+    FG_NORMAL,    // {N.x, N.y, N.z, gl depth of the children}
+    FG_ATT,       // attenuation of the node
+    FG_GEN,       // {v0, v1, v2, v3} of the generator state behind the last child still on the stack
+    FG_GEN2,      // {v4, d, children still on the stack, -}
+    FG_GROUPS
+};
+static_assert(WF_FRAME_PLANES == 4u * FG_GROUPS, "frame = FG_GROUPS groups of four words");
 // Shade records: three arrays of 16-byte groups behind WfArgs::work, indexed by record (cap_work records each), so
 // that a wave's consecutive records are one contiguous run per array and every access is a 16-byte one:
 //   point  [wi]           {P.x, P.y, P.z, primitive | ordinal << 8}           filter, resolve, shade
@@ -102,6 +111,9 @@ DI uint32_t f2u(float x) { return __float_as_uint(x); }
 // a few neighbouring kilobytes instead of pieces one whole image apart.
 DI size_t slot_at(const WfArgs& w, uint32_t k, size_t lp) { return ((lp >> 6) * w.quota + k) * 64u + (lp & 63u); }
 DI size_t slot_pixel(const WfArgs& w, size_t slot) { return (slot / ((size_t)w.quota * 64u)) * 64u + (slot & 63u); }
+DI uint4* frame_at(const WfArgs& w, uint32_t level, size_t lp) { // group g of the frame: [g * w.n_lp]
+    return reinterpret_cast<uint4*>(w.frames) + ((size_t)level * FG_GROUPS) * w.n_lp + lp;
+}
 DI uint4* rec_point(const WfArgs& w) { return reinterpret_cast<uint4*>(w.work); }
 DI uint4* rec_surface(const WfArgs& w) { return reinterpret_cast<uint4*>(w.work) + (size_t)w.cap_work; }
 DI uint4* rec_gen(const WfArgs& w) { return reinterpret_cast<uint4*>(w.work) + (size_t)w.cap_work * 4u; }
@@ -1323,42 +1335,32 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                         waiting = t_level >= 2u; // whether to subdivide depends on the four colours (main.cu:283-300)
                     }
                 } else {
-                    uint32_t* f = w.frames + ((size_t)(nframes - 1u) * WF_FRAME_PLANES) * n_lp + lp;
-                    const uint32_t cdepth = f[FR_CHILD_DEPTH * n_lp];
+                    uint4* f = frame_at(w, nframes - 1u, lp);
+                    const uint4 fn = f[FG_NORMAL * n_lp];
+                    const uint32_t cdepth = fn.w;
                     if (COOP && cdepth == 0u) {
                         want_coop = true; // the wave expands these children together, below
                     } else {
                         // pop the next child of the innermost frame (children leave last-to-first); its two
                         // draws are the last ones before the frame's generator state
                         PROF_LANES(2);
-                        Rng rv;
-                        rv.v0 = f[(FR_RNG + 0) * n_lp];
-                        rv.v1 = f[(FR_RNG + 1) * n_lp];
-                        rv.v2 = f[(FR_RNG + 2) * n_lp];
-                        rv.v3 = f[(FR_RNG + 3) * n_lp];
-                        rv.v4 = f[(FR_RNG + 4) * n_lp];
-                        rv.d = f[(FR_RNG + 5) * n_lp];
+                        const uint4 fp = f[FG_POINT * n_lp], fa = f[FG_ATT * n_lp], fg = f[FG_GEN * n_lp], fg2 = f[FG_GEN2 * n_lp];
+                        Rng rv = Rng{fg.x, fg.y, fg.z, fg.w, fg2.x, fg2.y};
                         float r2 = rng_current_uniform(rv);
                         rng_unstep(rv);
                         float r1 = rng_current_uniform(rv);
                         rng_unstep(rv);
-                        V3 hp = mk3(u2f(f[(FR_P + 0) * n_lp]), u2f(f[(FR_P + 1) * n_lp]), u2f(f[(FR_P + 2) * n_lp]));
-                        V3 hn = mk3(u2f(f[(FR_N + 0) * n_lp]), u2f(f[(FR_N + 1) * n_lp]), u2f(f[(FR_N + 2) * n_lp]));
-                        V4 patt = V4{u2f(f[(FR_ATT + 0) * n_lp]), u2f(f[(FR_ATT + 1) * n_lp]), u2f(f[(FR_ATT + 2) * n_lp]),
-                                     u2f(f[(FR_ATT + 3) * n_lp])};
-                        const float* fpr = s_prim[f[FR_GEOM * n_lp]];
+                        V3 hp = mk3(u2f(fp.x), u2f(fp.y), u2f(fp.z));
+                        V3 hn = mk3(u2f(fn.x), u2f(fn.y), u2f(fn.z));
+                        V4 patt = V4{u2f(fa.x), u2f(fa.y), u2f(fa.z), u2f(fa.w)};
+                        const float* fpr = s_prim[fp.w];
                         V4 pdiff = V4{fpr[12], fpr[13], fpr[14], fpr[15]};
-                        uint32_t rem = f[FR_REMAINING * n_lp] - 1u;
+                        uint32_t rem = fg2.z - 1u;
                         if (rem == 0u) {
                             --nframes;
                         } else {
-                            f[FR_REMAINING * n_lp] = rem;
-                            f[(FR_RNG + 0) * n_lp] = rv.v0;
-                            f[(FR_RNG + 1) * n_lp] = rv.v1;
-                            f[(FR_RNG + 2) * n_lp] = rv.v2;
-                            f[(FR_RNG + 3) * n_lp] = rv.v3;
-                            f[(FR_RNG + 4) * n_lp] = rv.v4;
-                            f[(FR_RNG + 5) * n_lp] = rv.d;
+                            f[FG_GEN * n_lp] = make_uint4(rv.v0, rv.v1, rv.v2, rv.v3);
+                            f[FG_GEN2 * n_lp] = make_uint4(rv.v4, rv.d, rem, 0u);
                         }
                         --on_stack;
                         child_ray(hp, hn, patt, pdiff, r1, r2, inv_ind, cur_o, cur_d, cur_att);
@@ -1449,27 +1451,13 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                         for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
                     }
                     if (accepted > 0u) {
-                        uint32_t* f = w.frames + ((size_t)nframes * WF_FRAME_PLANES) * n_lp + lp;
+                        uint4* f = frame_at(w, nframes, lp);
                         ++nframes;
-                        f[(FR_P + 0) * n_lp] = f2u(n_P.x);
-                        f[(FR_P + 1) * n_lp] = f2u(n_P.y);
-                        f[(FR_P + 2) * n_lp] = f2u(n_P.z);
-                        f[(FR_N + 0) * n_lp] = f2u(n_N.x);
-                        f[(FR_N + 1) * n_lp] = f2u(n_N.y);
-                        f[(FR_N + 2) * n_lp] = f2u(n_N.z);
-                        f[(FR_ATT + 0) * n_lp] = f2u(n_att.x);
-                        f[(FR_ATT + 1) * n_lp] = f2u(n_att.y);
-                        f[(FR_ATT + 2) * n_lp] = f2u(n_att.z);
-                        f[(FR_ATT + 3) * n_lp] = f2u(n_att.w);
-                        f[(FR_RNG + 0) * n_lp] = rng.v0;
-                        f[(FR_RNG + 1) * n_lp] = rng.v1;
-                        f[(FR_RNG + 2) * n_lp] = rng.v2;
-                        f[(FR_RNG + 3) * n_lp] = rng.v3;
-                        f[(FR_RNG + 4) * n_lp] = rng.v4;
-                        f[(FR_RNG + 5) * n_lp] = rng.d;
-                        f[FR_GEOM * n_lp] = n_geom;
-                        f[FR_REMAINING * n_lp] = accepted;
-                        f[FR_CHILD_DEPTH * n_lp] = n_depth - 1u;
+                        f[FG_POINT * n_lp] = make_uint4(f2u(n_P.x), f2u(n_P.y), f2u(n_P.z), n_geom);
+                        f[FG_NORMAL * n_lp] = make_uint4(f2u(n_N.x), f2u(n_N.y), f2u(n_N.z), n_depth - 1u);
+                        f[FG_ATT * n_lp] = make_uint4(f2u(n_att.x), f2u(n_att.y), f2u(n_att.z), f2u(n_att.w));
+                        f[FG_GEN * n_lp] = make_uint4(rng.v0, rng.v1, rng.v2, rng.v3);
+                        f[FG_GEN2 * n_lp] = make_uint4(rng.v4, rng.d, accepted, 0u);
                         on_stack += accepted;
                     }
                     for (uint32_t k = 2u * accepted; k < 2u * a.ind_rays; ++k) rng_step(rng);
@@ -1488,7 +1476,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                 uint32_t* own_tab = s_coop[threadIdx.x >> 6]; // [kCoopOwners][OW_WORDS], this wave's
                 uint32_t my_rem = 0, my_n = 0;
                 if (want_coop) {
-                    my_rem = w.frames[((size_t)(nframes - 1u) * WF_FRAME_PLANES + FR_REMAINING) * n_lp + lp];
+                    my_rem = frame_at(w, nframes - 1u, lp)[FG_GEN2 * n_lp].z;
                     my_n = my_rem < quota - cnt ? my_rem : quota - cnt;
                     if (my_n > kCoopBatch) my_n = kCoopBatch;
                 }
@@ -1529,12 +1517,12 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                     const uint32_t* oj = own_tab + j * OW_WORDS;
                     const uint32_t o_lp = oj[OW_LP], o_rem = oj[OW_REM];
                     V3 c_ray_d = mk3(u2f(oj[OW_RAY_D + 0]), u2f(oj[OW_RAY_D + 1]), u2f(oj[OW_RAY_D + 2]));
-                    const uint32_t* f = w.frames + ((size_t)(oj[OW_NFRAMES] - 1u) * WF_FRAME_PLANES) * n_lp + o_lp;
-                    const V3 hp = mk3(u2f(f[(FR_P + 0) * n_lp]), u2f(f[(FR_P + 1) * n_lp]), u2f(f[(FR_P + 2) * n_lp]));
-                    const V3 hn = mk3(u2f(f[(FR_N + 0) * n_lp]), u2f(f[(FR_N + 1) * n_lp]), u2f(f[(FR_N + 2) * n_lp]));
-                    const V4 patt = V4{u2f(f[(FR_ATT + 0) * n_lp]), u2f(f[(FR_ATT + 1) * n_lp]), u2f(f[(FR_ATT + 2) * n_lp]),
-                                       u2f(f[(FR_ATT + 3) * n_lp])};
-                    const float* fpr = s_prim[f[FR_GEOM * n_lp]];
+                    const uint4* f = frame_at(w, oj[OW_NFRAMES] - 1u, o_lp);
+                    const uint4 fp = f[FG_POINT * n_lp], fn = f[FG_NORMAL * n_lp], fa = f[FG_ATT * n_lp];
+                    const V3 hp = mk3(u2f(fp.x), u2f(fp.y), u2f(fp.z));
+                    const V3 hn = mk3(u2f(fn.x), u2f(fn.y), u2f(fn.z));
+                    const V4 patt = V4{u2f(fa.x), u2f(fa.y), u2f(fa.z), u2f(fa.w)};
+                    const float* fpr = s_prim[fp.w];
                     const V4 pdiff = V4{fpr[12], fpr[13], fpr[14], fpr[15]};
                     // the c-th child of its owner to leave the stack: child rem-1-c, drawn as pair rem-1-c
                     const uint32_t child = o_rem - 1u - (act ? p - oj[OW_PRE] : 0u);
@@ -1649,7 +1637,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                     ray_d = mk3(u2f(ow[OW_RAY_D + 0]), u2f(ow[OW_RAY_D + 1]), u2f(ow[OW_RAY_D + 2]));
                     on_stack -= my_n;
                     if (my_rem == my_n) --nframes;
-                    else w.frames[((size_t)(nframes - 1u) * WF_FRAME_PLANES + FR_REMAINING) * n_lp + lp] = my_rem - my_n;
+                    else frame_at(w, nframes - 1u, lp)[FG_GEN2 * n_lp].z = my_rem - my_n;
                 }
             }
         }
