@@ -92,10 +92,15 @@ enum WfCounter : uint32_t {
     WF_CTR_WORK = 0,    // record indices handed out this round
     WF_CTR_ACTIVE = 1,  // pixels not finished after this round
     WF_CTR_QUEUE = 2,   // undecided shadow rays queued by the filter kernel (cleared per round, or per filter batch)
-    WF_CTR_ERROR = 5,   // non-zero: a capacity was exceeded (results invalid); sticky for the frame
-    WF_CTR_QOVERFLOW = 6, // non-zero: the ray queue was full and rays were dropped; sticky for the frame
+    WF_CTR_ERROR = 14,  // non-zero: a capacity was exceeded (results invalid); sticky for the frame
+    WF_CTR_QOVERFLOW = 15, // non-zero: the ray queue was full and rays were dropped; sticky for the frame
     WF_CTR_COUNT = 16,
 };
+// Behind the counters: the cursors the filter waves (one set per light) and the resolve waves (the last set) take
+// their groups of 64 records / rays from.  A set is WF_CURSOR_PARTS cursors, each in a 128-byte line of its own and
+// each over every WF_CURSOR_PARTS-th group: atomics on one address take about 10 ns each, whoever issues them.
+constexpr uint32_t WF_CURSOR_PARTS = 32, WF_CURSOR_STRIDE = 32, WF_CURSOR_SETS = CRT_MAX_LIGHTS + 1;
+constexpr uint32_t WF_CURSOR_WORDS = WF_CURSOR_SETS * WF_CURSOR_PARTS * WF_CURSOR_STRIDE;
 // True when the wavefront pipeline implements these settings (all of them).
 bool wavefront_supports(const RenderArgs& args);
 // Frees / (re)allocates the workspace for this launch; returns hipSuccess or the allocation error.

@@ -812,6 +812,46 @@ DI uint32_t record_light_class(ScenePtr sc, uint32_t li, const LightF& lf, V3 P)
     return have_sure ? 2u : 1u;
 }
 
+// Hands a wave the groups (of 64 records or rays) of a launch, a few at a time: cursor set `set` of the counter
+// block, one cursor per partition, partition p = the groups g with g % WF_CURSOR_PARTS == p.  A wave starts at the
+// partition of its workgroup and moves on to the next three when one is used up, so the waves end together although
+// the groups' costs differ widely (a fixed stride left the last waves running alone; a wave that looked into every
+// partition before it ends would add tens of thousands of atomics to a small launch).
+struct GroupFeed {
+    uint32_t part, parts_left, next, end, chunk, n_groups;
+    uint32_t* cursors;
+};
+DI GroupFeed feed_begin(const WfArgs& w, uint32_t set, uint32_t n_groups) {
+    GroupFeed f;
+    f.part = blockIdx.x % WF_CURSOR_PARTS;
+    f.parts_left = 4u; // its own partition and the next three: every partition is the same sample of the launch's groups
+    f.next = f.end = 0u;
+    uint32_t chunk = n_groups / (gridDim.x * 8u); // about eight turns per wave
+    f.chunk = chunk < 1u ? 1u : (chunk > 8u ? 8u : chunk);
+    f.n_groups = n_groups;
+    f.cursors = w.ctrs + WF_CTR_COUNT + (size_t)set * WF_CURSOR_PARTS * WF_CURSOR_STRIDE;
+    return f;
+}
+DI bool feed_next(GroupFeed& f, uint32_t lane, uint32_t& g) { // wave-uniform
+    while (f.next == f.end) {
+        if (f.parts_left == 0u) return false;
+        const uint32_t in_part = f.part < f.n_groups ? (f.n_groups - f.part + WF_CURSOR_PARTS - 1u) / WF_CURSOR_PARTS : 0u;
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&f.cursors[f.part * WF_CURSOR_STRIDE], f.chunk);
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        if (c < in_part) {
+            f.next = c;
+            f.end = c + f.chunk < in_part ? c + f.chunk : in_part;
+        } else {
+            f.part = (f.part + 1u) % WF_CURSOR_PARTS;
+            --f.parts_left;
+        }
+    }
+    g = f.next * WF_CURSOR_PARTS + f.part;
+    ++f.next;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------- trace
 #ifndef CRT_TRACE_BLOCK_WAVES
 #define CRT_TRACE_BLOCK_WAVES 4
@@ -1756,13 +1796,16 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
     const size_t cw = w.cap_work;
     if (w_end == kFromCounter) w_end = min(w.ctrs[WF_CTR_WORK], w.cap_work);
     const uint32_t n_lights = sc->n_lights;
+    const uint32_t n_groups = w_begin < w_end ? (w_end - w_begin + 63u) / 64u : 0u;
     uint32_t draws_before = 0; // draws of one record that precede light li (AreaLight.hpp:342-343 per sample)
     for (uint32_t li = 0; li < n_lights; ++li) {
         const DevLight CRT_CONST* L = &sc->lights[li];
         if (L->kind != CRT_LIGHT_AREA || !L->initialized) continue; // no draws (Light.hpp:92-111, AreaLight.hpp:586)
         const uint32_t S = L->shadow_samples;
         const LightF lf = load_lightf(L);
-        for (uint32_t base = blockIdx.x * 64u; w_begin < w_end && base < w_end - w_begin; base += gridDim.x * 64u) {
+        GroupFeed feed = feed_begin(w, li, n_groups);
+        for (uint32_t g = 0; feed_next(feed, lane, g);) {
+            const uint32_t base = g * 64u;
             const uint32_t wi = w_begin + base + lane;
             const uint32_t wr = wi < w_end ? wi : w_begin;
             const uint4 pt = rec_point(w)[wr];
@@ -1932,7 +1975,10 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
     // the queue's fill is whatever the filter kernel left in the device counter
     const uint32_t qcount = min(w.ctrs[WF_CTR_QUEUE], w.qcap);
     uint32_t glass_tally = 0;
-    for (uint32_t base = blockIdx.x * 64u; base < qcount; base += gridDim.x * 64u) {
+    // (a ray that meets glass costs several times one that does not)
+    GroupFeed feed = feed_begin(w, CRT_MAX_LIGHTS, (qcount + 63u) / 64u);
+    for (uint32_t rg = 0; feed_next(feed, lane, rg);) {
+        const uint32_t base = rg * 64u;
         bool act = base + lane < qcount;
         const size_t idx = (size_t)base + lane;
         uint32_t key = 0;
@@ -2360,7 +2406,7 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
         e = hipMalloc(p, bytes);
         total += bytes;
     };
-    grab((void**)&ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t));
+    grab((void**)&ws.ctrs, (WF_CTR_COUNT + WF_CURSOR_WORDS) * sizeof(uint32_t));
     grab((void**)&ws.state, (size_t)WF_STATE_PLANES * n_lp * 4u);
     grab((void**)&ws.frames, (size_t)levels * WF_FRAME_PLANES * n_lp * 4u);
     grab((void**)&ws.tags, (size_t)quota * n_lp);
@@ -2467,6 +2513,7 @@ hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const G
     for (uint32_t round = 0;; ++round) {
         uint32_t* host = ws.ctrs_host + (size_t)(round % WF_CTR_RING) * WF_CTR_COUNT;
         e = hipMemsetAsync(ws.ctrs, 0, WF_CTR_ERROR * sizeof(uint32_t), stream); // the flags behind it are sticky
+        if (e == hipSuccess) e = hipMemsetAsync(ws.ctrs + WF_CTR_COUNT, 0, WF_CURSOR_WORDS * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
         // slot tags default to TAG_ADD (0): the trace kernel stores only the rare end-of-call / end-of-pixel marks
         e = hipMemsetAsync(ws.tags, 0, (size_t)w.quota * ws.n_lp, stream);
@@ -2508,6 +2555,7 @@ hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const G
                 const uint32_t groups = (b1 - b0 + 63u) / 64u;
                 const uint32_t fgrid = groups < g.filter ? groups : g.filter;
                 e = hipMemsetAsync(ws.ctrs + WF_CTR_QUEUE, 0, sizeof(uint32_t), stream);
+                if (e == hipSuccess) e = hipMemsetAsync(ws.ctrs + WF_CTR_COUNT, 0, WF_CURSOR_WORDS * sizeof(uint32_t), stream);
                 if (e != hipSuccess) return e;
                 if (coop) WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel<true>, dim3(fgrid), dim3(64), 0, stream, w, b0, b1));
                 else WF_TIMED(WF_K_FILTER, hipLaunchKernelGGL(wf_filter_kernel<false>, dim3(fgrid), dim3(64), 0, stream, w, b0, b1));
@@ -2629,12 +2677,9 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         g.filter = cus * 4u * CRT_WF_FILTER_WAVES;
         if (g.filter > kMaxFilterWaves) g.filter = kMaxFilterWaves;
         if (g.filter > groups) g.filter = groups;
-        // resolve: grid-stride over the queue; about one block per 32 groups of rays if a twentieth of the
-        // shadow rays stay undecided (a block's set-up costs about as much as two groups)
-        const uint64_t rays = (uint64_t)cap_used * (args.max_shadow_rays ? args.max_shadow_rays : 1u);
-        uint64_t rgrid = rays / (64u * 32u * 20u);
-        if (rgrid < cus * 16u) rgrid = cus * 16u;
-        if (rgrid > 131072u) rgrid = 131072u;
+        // resolve: as many waves as the device keeps resident (57 registers: eight per SIMD); they take the queue's
+        // groups of 64 rays from a cursor
+        uint64_t rgrid = (uint64_t)cus * 32u;
         if (rgrid > (ws.qcap + 63u) / 64u) rgrid = (ws.qcap + 63u) / 64u;
         g.resolve = (uint32_t)rgrid;
         g.shade = groups;
