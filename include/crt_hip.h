@@ -253,7 +253,7 @@ int crt_set_pipeline(crt_ctx* ctx, int pipeline);
  *   CRT_TRACE_COOPERATIVE  a wave owns 8 pixels and its 64 lanes take one child ray each: twice the
  *                          instructions, but a pixel's dependent chain gets 10x shorter, which wins when
  *                          every wave would otherwise sit alone on its SIMD (the shards of a multi-GPU job)
- *   CRT_TRACE_AUTO         by launch size (default): below 100 000 pixels all units cooperative; up to
+ *   CRT_TRACE_AUTO         by launch size (default): below 200 000 pixels all units cooperative; up to
  *                          400 000 the few per cent with the highest cost estimate, next to the per-pixel
  *                          kernel on a second stream (they are what the launch would end up waiting for);
  *                          above that per-pixel only
