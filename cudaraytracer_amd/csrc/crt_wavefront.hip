@@ -101,6 +101,8 @@ struct WfArgs {
     uint32_t qchunk;           // queue entries a filter wave reserves at a time (a multiple of 64)
     const uint32_t* unit_order; // trace: launch slot -> work unit, most expensive first; null = identity
     float* draws;              // cooperative trace: [2 * CRT_RAY_STACK][n_lp] child draws of the innermost leaf node
+    uint32_t work_static;      // record indices [0, work_static): the first chunk of every per-pixel trace wave, by its place
+                               // in the launch; WF_CTR_WORK counts the chunks handed out behind them
     const uint32_t* coop_tabs; // cooperative trace: kCoopTables rng_jump tables in device memory, table k-1 jumps k shaded points' worth of draws
 };
 
@@ -111,6 +113,10 @@ DI uint32_t f2u(float x) { return __float_as_uint(x); }
 // a few neighbouring kilobytes instead of pieces one whole image apart.
 DI size_t slot_at(const WfArgs& w, uint32_t k, size_t lp) { return ((lp >> 6) * w.quota + k) * 64u + (lp & 63u); }
 DI size_t slot_pixel(const WfArgs& w, size_t slot) { return (slot / ((size_t)w.quota * 64u)) * 64u + (slot & 63u); }
+DI uint32_t records_handed_out(const WfArgs& w) { // record indices below this may hold a record
+    const uint32_t n = w.work_static + w.ctrs[WF_CTR_WORK];
+    return n < w.cap_work ? n : w.cap_work;
+}
 DI uint4* frame_at(const WfArgs& w, uint32_t level, size_t lp) { // group g of the frame: [g * w.n_lp]
     return reinterpret_cast<uint4*>(w.frames) + ((size_t)level * FG_GROUPS) * w.n_lp + lp;
 }
@@ -1055,7 +1061,7 @@ DI uint32_t reserve_records(const WfArgs& w, WorkCursor& wc, uint64_t em, uint32
     const bool need_chunk = wc.used + n_emit > kWorkChunk;
     uint32_t new_base = 0;
     if (need_chunk) {
-        if (lane == (uint32_t)__builtin_ctzll(em)) new_base = atomicAdd(&w.ctrs[WF_CTR_WORK], kWorkChunk);
+        if (lane == (uint32_t)__builtin_ctzll(em)) new_base = w.work_static + atomicAdd(&w.ctrs[WF_CTR_WORK], kWorkChunk);
         new_base = (uint32_t)__builtin_amdgcn_readlane((int)new_base, __builtin_ctzll(em));
     }
     const uint32_t my_pos = wc.used + lane_rank(em);
@@ -1283,7 +1289,10 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
     uint32_t cnt = 0; // result slots filled this round
     uint32_t cnt_shade = 0, cnt_expand = 0;
     const uint32_t quota = w.quota;
-    WorkCursor wc = {0u, kWorkChunk, false};
+    // A per-pixel wave's first chunk of record indices is its own by its place in the launch: one atomic per wave on
+    // one counter at the start of the kernel, 8 100 of them at 10 ns each, was a third of a gl_iter 0 frame's trace
+    // time.  (The cooperative kernel has eight times the waves, and most of their first chunks would stay empty.)
+    WorkCursor wc = {COOP ? 0u : wave_slot * kWorkChunk, COOP ? kWorkChunk : 0u, !COOP};
 #ifdef CRT_TRACE_PROFILE // build with -DCRT_TRACE_PROFILE: every 37th wave prints its steps and the cycles per section
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = 0, prof_iters = 0;
 #define PROF_MARK(k)                                   \
@@ -1794,7 +1803,7 @@ __global__ void __launch_bounds__(64, CRT_WF_FILTER_WAVES) wf_filter_kernel(WfAr
     uint32_t rqn = 0; // wave-uniform fill of rq
     uint32_t tally = 0;
     const size_t cw = w.cap_work;
-    if (w_end == kFromCounter) w_end = min(w.ctrs[WF_CTR_WORK], w.cap_work);
+    if (w_end == kFromCounter) w_end = records_handed_out(w);
     const uint32_t n_lights = sc->n_lights;
     const uint32_t n_groups = w_begin < w_end ? (w_end - w_begin + 63u) / 64u : 0u;
     uint32_t draws_before = 0; // draws of one record that precede light li (AreaLight.hpp:342-343 per sample)
@@ -1853,7 +1862,7 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
     const uint32_t lane = threadIdx.x;
     const uint32_t n_lights = sc->n_lights;
     unsigned long long decided = 0, bad = 0;
-    if (w_end == kFromCounter) w_end = min(w.ctrs[WF_CTR_WORK], w.cap_work);
+    if (w_end == kFromCounter) w_end = records_handed_out(w);
     for (uint32_t base = blockIdx.x * 64u; w_begin < w_end && base < w_end - w_begin; base += gridDim.x * 64u) {
         const uint32_t wi = w_begin + base + lane;
         const uint32_t wr = wi < w_end ? wi : w_begin;
@@ -2061,7 +2070,7 @@ DI void shade_record(const WfArgs& w, ScenePtr sc, uint32_t wi);
 template <bool CLIP>
 __global__ void __launch_bounds__(CRT_SHADE_BLOCK, CRT_SHADE_WAVES) wf_shade_kernel(WfArgs w) {
     const uint32_t wi = blockIdx.x * (uint32_t)CRT_SHADE_BLOCK + threadIdx.x;
-    if (wi >= min(w.ctrs[WF_CTR_WORK], w.cap_work)) return;
+    if (wi >= records_handed_out(w)) return;
     shade_record<CLIP>(w, (ScenePtr)w.r.scene, wi);
 }
 template <bool CLIP>
@@ -2546,7 +2555,8 @@ hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const G
             e = hipMemcpyAsync(host, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
             if (e != hipSuccess) return e;
-            const uint32_t n_work = host[WF_CTR_WORK] < ws.cap_work ? host[WF_CTR_WORK] : ws.cap_work;
+            const uint64_t handed_out = (uint64_t)w.work_static + host[WF_CTR_WORK];
+            const uint32_t n_work = handed_out < ws.cap_work ? (uint32_t)handed_out : ws.cap_work;
             uint64_t batch = g.qusable / rays_per_record / 64u * 64u;
             if (batch == 0) return hipErrorInvalidValue; // a single group's shadow rays exceed the queue
             if (batch > 0x40000000ull) batch = 0x40000000ull;
@@ -2649,6 +2659,7 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     w.jump_n[1] = ws.jump_n[1];
     w.draws = ws.draws;
     w.coop_tabs = ws.coop_tabs;
+    w.work_static = 0u;
     w.unit_order = nullptr;
     ws.single_round = args.aa_iter <= 1u && slots_per_pixel(args) <= ws.quota;
     const bool coop = args.cooperative != 0u && args.gl_iter != 0u;
@@ -2723,6 +2734,7 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     // The order is reused while scene, camera and mapping stay the same (same estimate), except by mixed
     // launches: a half-frame launch with both trace kernels measured 0.6 ms slower when it is queued behind
     // the previous frame instead of entering an idle GPU after the pre-pass's host round trip.
+    w.work_static = (args.n_units - n_coop) * kWorkChunk; // the per-pixel waves' first chunks
     const bool mixed = n_coop != 0u && n_coop != args.n_units;
     if (args.gl_iter != 0u && args.n_units > 1u && !mixed && ws.order_valid && same_pixel_mapping(args, ws.order_key)) {
         w.unit_order = ws.unit_order;
