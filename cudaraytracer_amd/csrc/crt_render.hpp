@@ -58,7 +58,7 @@ struct WfWorkspace {
     uint32_t* slot_count = nullptr; // [n_lp]
     float* px_acc = nullptr;        // [3][n_lp] float4: colour of the running color() call, pixel accumulator, first corner of the running AA task
     uint32_t* aa_verdict = nullptr; // [n_lp]: the sum kernel's verdict on a finished level >= 2 AA task
-    uint32_t* work = nullptr;       // shade records: cap_work x WF_WORK_PLANES words, in three arrays of 16-byte groups
+    uint32_t* work = nullptr;       // shade records: cap_work x WF_WORK_PLANES words, in six arrays of 16-byte groups
     uint32_t* shadow_cnt = nullptr; // [n_lights][cap_work]
     uint32_t* queue = nullptr;      // [3][qcap]
     uint32_t* jump_dev = nullptr;   // two generator jump tables

@@ -73,14 +73,18 @@ enum : uint32_t {
     FG_GROUPS
 };
 static_assert(WF_FRAME_PLANES == 4u * FG_GROUPS, "frame = FG_GROUPS groups of four words");
-// Shade records: three arrays of 16-byte groups behind WfArgs::work, indexed by record (cap_work records each), so
-// that a wave's consecutive records are one contiguous run per array and every access is a 16-byte one:
-//   point  [wi]           {P.x, P.y, P.z, primitive | ordinal << 8}           filter, resolve, shade
-//   surface[3 wi + 0..2]  {N.x, N.y, N.z, result slot} {view.x, view.y, view.z, att.w} {att.x, att.y, att.z, -}   shade
-//   gen    [2 wi + 0..1]  {v0, v1, v2, v3} {v4, d, -, -}                       filter (the records it samples)
+// Shade records: six arrays of 16-byte groups behind WfArgs::work, each indexed by record (cap_work entries), so that
+// a wave's consecutive records are one contiguous kilobyte per array and access: every store instruction of the trace
+// kernel then writes whole lines (they are streamed past the caches, store_streaming), every load reads whole lines.
+//   0  {P.x, P.y, P.z, primitive | ordinal << 8}     filter, resolve, shade
+//   1  {N.x, N.y, N.z, result slot}                  shade
+//   2  {view.x, view.y, view.z, att.w}               shade
+//   3  {att.x, att.y, att.z, -}                      shade
+//   4  {v0, v1, v2, v3}   5  {v4, d, -, -}           filter (the records it samples)
 // (Word planes, one per field, had every kernel gather 256-byte pieces from up to 21 streams 650 MB apart: the shade
-// kernel ran at 2.5 TB/s whatever its arithmetic.)
-static_assert(WF_WORK_PLANES == 24, "1 + 3 + 2 groups of four words per record");
+// kernel ran at 2.5 TB/s whatever its arithmetic.  One record's surface groups next to each other, 48 bytes apart
+// from lane to lane, made three instructions share every line: 0.2 ms slower per 720x720 gl_iter 1 frame.)
+static_assert(WF_WORK_PLANES == 24, "six groups of four words per record");
 
 struct WfArgs {
     RenderArgs r;
@@ -132,7 +136,7 @@ DI uint4* rec_point(const WfArgs& w) { return reinterpret_cast<uint4*>(w.work); 
 DI uint4* rec_surface(const WfArgs& w) { return reinterpret_cast<uint4*>(w.work) + (size_t)w.cap_work; }
 DI uint4* rec_gen(const WfArgs& w) { return reinterpret_cast<uint4*>(w.work) + (size_t)w.cap_work * 4u; }
 DI Rng rec_load_gen(const WfArgs& w, uint32_t wi) {
-    const uint4 g0 = rec_gen(w)[2u * (size_t)wi], g1 = rec_gen(w)[2u * (size_t)wi + 1u];
+    const uint4 g0 = rec_gen(w)[wi], g1 = rec_gen(w)[(size_t)w.cap_work + wi];
     return Rng{g0.x, g0.y, g0.z, g0.w, g1.x, g1.y};
 }
 
@@ -1045,13 +1049,14 @@ DI void store_record(const WfArgs& w, uint32_t wi, V3 P, V3 N, V3 view, V4 att, 
     PROF_LANES(11);
     if (wi < w.cap_work) {
         store_streaming(rec_point(w) + wi, make_uint4(f2u(P.x), f2u(P.y), f2u(P.z), geom | (ordinal << 8)));
-        uint4* sf = rec_surface(w) + 3u * (size_t)wi;
+        const size_t cw_ = w.cap_work;
+        uint4* sf = rec_surface(w) + wi;
         store_streaming(sf, make_uint4(f2u(N.x), f2u(N.y), f2u(N.z), slot));
-        store_streaming(sf + 1, make_uint4(f2u(view.x), f2u(view.y), f2u(view.z), f2u(att.w)));
-        store_streaming(sf + 2, make_uint4(f2u(att.x), f2u(att.y), f2u(att.z), 0u));
-        uint4* gn = rec_gen(w) + 2u * (size_t)wi;
+        store_streaming(sf + cw_, make_uint4(f2u(view.x), f2u(view.y), f2u(view.z), f2u(att.w)));
+        store_streaming(sf + 2 * cw_, make_uint4(f2u(att.x), f2u(att.y), f2u(att.z), 0u));
+        uint4* gn = rec_gen(w) + wi;
         store_streaming(gn, make_uint4(rng.v0, rng.v1, rng.v2, rng.v3));
-        store_streaming(gn + 1, make_uint4(rng.v4, rng.d, 0u, 0u));
+        store_streaming(gn + cw_, make_uint4(rng.v4, rng.d, 0u, 0u));
     } else {
         w.ctrs[WF_CTR_ERROR] = 1u;
     }
@@ -1901,7 +1906,7 @@ __global__ void __launch_bounds__(64) wf_audit_kernel(WfArgs w, uint32_t w_begin
                 }
 #ifdef CRT_SHADE_TRACE
                 if (act) {
-                    const uint32_t lp_ = (uint32_t)slot_pixel(w, rec_surface(w)[3u * (size_t)wr].w);
+                    const uint32_t lp_ = (uint32_t)slot_pixel(w, rec_surface(w)[wr].w);
                     const PixelMap pm_ = map_pixel(w.r, lp_ / 64u, lp_ % 64u);
                     if (pm_.valid && pm_.j * w.r.nx + pm_.i == (uint32_t)(CRT_SHADE_TRACE)) {
                         V3 o_, d_;
@@ -2085,8 +2090,8 @@ template <bool CLIP>
 DI void shade_record(const WfArgs& w, ScenePtr sc, uint32_t wi) {
     const size_t cw = w.cap_work;
     const uint4 pt = rec_point(w)[wi];
-    const uint4* sf = rec_surface(w) + 3u * (size_t)wi;
-    const uint4 s0 = sf[0], s1 = sf[1], s2 = sf[2];
+    const uint4* sf = rec_surface(w) + wi;
+    const uint4 s0 = sf[0], s1 = sf[cw], s2 = sf[2 * cw];
     const V3 P = mk3(u2f(pt.x), u2f(pt.y), u2f(pt.z));
     const V3 N = mk3(u2f(s0.x), u2f(s0.y), u2f(s0.z));
     const V3 view = mk3(u2f(s1.x), u2f(s1.y), u2f(s1.z));
