@@ -190,6 +190,13 @@ struct Stage {
     uint32_t q_next, q_end; // the wave's piece of the queue: next free entry, end (q_next == q_end: none)
 };
 constexpr uint32_t kNoRay = 0xffffffffu; // queue key of an entry that holds no ray
+// A queued ray's key: its shade record's index in the low kRecBits bits, its light above them.
+#ifndef CRT_REC_BITS
+#define CRT_REC_BITS 28
+#endif
+constexpr uint32_t kRecBits = CRT_REC_BITS, kRecMask = (1u << kRecBits) - 1u;
+constexpr uint64_t kRecLimit = 1ull << kRecBits;
+static_assert(CRT_MAX_LIGHTS <= (1u << (32u - kRecBits)), "the light must fit above the record index");
 
 // Moves `n` staged entries (n <= 64) to the queue.  A wave reserves the queue in pieces of w.qchunk entries
 // (one atomic on the device counter per piece: atomics on one address are served one after the other, about
@@ -1803,7 +1810,7 @@ DI void filter_batch(const WfArgs& w, ScenePtr sc, uint32_t li, const LightF& lf
     if (ORDINALS && __any(ordinal != 0u)) ordinal_jump(rng, ordinal, w); // a record of a cooperative batch (powers of one map: order is free)
     const RecordFilter rf = make_record_filter(sc, li, lf, P);
     uint32_t shadowed = 0;
-    const uint32_t key = wi | (li << 28);
+    const uint32_t key = wi | (li << kRecBits);
     uint32_t s = 0;
     if (rf.poly && rf.rest_mask == 0) { // every candidate has a slot: the sample loop is polynomial evaluation only
         for (; s + 5u <= S; s += 5u) filter_block<5, true>(w, sc, lf, rf, act, rng, key, shadowed, stg, st, lane, tally);
@@ -1987,14 +1994,14 @@ DI void glass_batch(const WfArgs& w, ScenePtr sc, float (*gq_f)[kGlassCap], uint
     h.v = gq_f[8][slot];
     const uint32_t key = gq_u[0][slot];
     h.idx = (int)gq_u[1][slot];
-    const uint32_t my_light = key >> 28;
+    const uint32_t my_light = key >> kRecBits;
     const uint32_t n_lights = sc->n_lights;
     for (uint32_t li = 0; li < n_lights; ++li) {
         const bool mine = act && my_light == li;
         if (!__any(mine)) continue;
         const DevLight CRT_CONST* L = &sc->lights[li];
         if (mine && covered_through_glass(sc, L, o, d, h))
-            atomicAdd(&w.shadow_cnt[(size_t)li * w.cap_work + (key & 0x0fffffffu)], 1u);
+            atomicAdd(&w.shadow_cnt[(size_t)li * w.cap_work + (key & kRecMask)], 1u);
     }
     gq = base;
     __syncthreads();
@@ -2031,7 +2038,7 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
         } else {
             key = 0u;
         }
-        const uint32_t my_light = key >> 28;
+        const uint32_t my_light = key >> kRecBits;
         bool glass = false;
         V3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
         Hit h;
@@ -2050,7 +2057,7 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
                 // first pass of Light::_isCovered (Light.hpp:35-46)
                 h = closest_hit_masked(sc, o, d, x, shadow_candidates(sc, li, P));
                 if (h.idx >= 0) {
-                    if (h.mat_type != CRT_MAT_REFRACTIVE) atomicAdd(&w.shadow_cnt[(size_t)li * cw + (key & 0x0fffffffu)], 1u);
+                    if (h.mat_type != CRT_MAT_REFRACTIVE) atomicAdd(&w.shadow_cnt[(size_t)li * cw + (key & kRecMask)], 1u);
                     else glass = true;
                 }
             }
@@ -2351,7 +2358,7 @@ bool wavefront_supports(const RenderArgs& a) {
     const uint64_t n_lp = (uint64_t)a.n_units * 64u;
     if (n_lp == 0) return true;
     const uint64_t chunk_slack = (a.cooperative ? kCoopSplit : 1u) * 2u * kWorkChunk / 64u;
-    return ((1ull << 28) - 1u) / n_lp >= chunk_slack + 1u + kMinQuota;
+    return (kRecLimit - 1u) / n_lp >= chunk_slack + 1u + kMinQuota;
 }
 
 // Whether two launches map work units to pixels and rays the same way and walk trees of the same shape
@@ -2413,8 +2420,8 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     if (quota_max < 16u) quota_max = 16u; // what a round needs to make progress, whatever the limit says
     if (want > quota_max) want = quota_max;
     const uint64_t chunk_slack = (args.cooperative ? kCoopSplit : 1u) * 2u * kWorkChunk / 64u; // partly used chunks, per pixel slot
-    if ((want + chunk_slack + 1u) * n_lp >= (1ull << 28)) { // record index and light share one word
-        const uint64_t room = ((1ull << 28) - 1u) / n_lp;
+    if ((want + chunk_slack + 1u) * n_lp >= kRecLimit) { // record index and light share one word
+        const uint64_t room = (kRecLimit - 1u) / n_lp;
         if (room < chunk_slack + 1u + kMinQuota) return hipErrorOutOfMemory; // see wavefront_supports
         want = room - chunk_slack - 1u;
     }
