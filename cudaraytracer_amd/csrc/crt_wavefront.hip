@@ -2033,7 +2033,7 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
         if (act) {
             u = u2f(w.queue[(size_t)w.qcap + idx]);
             v = u2f(w.queue[2 * (size_t)w.qcap + idx]);
-            const uint4 pt = rec_point(w)[key & 0x0fffffffu];
+            const uint4 pt = rec_point(w)[key & kRecMask];
             P = mk3(u2f(pt.x), u2f(pt.y), u2f(pt.z));
         } else {
             key = 0u;
