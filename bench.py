@@ -3,6 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload gl0|gl1|gl2]
 
+With N > 1 and no rank environment the script starts its own ranks (`python -m torch.distributed.run`, one
+process per GPU, rendezvous on 127.0.0.1) before anything touches a GPU, passes their output through and
+exits with their status; started under torch.distributed.run it is one of those ranks.  `--dry-run` runs the
+same launcher and the same gather/scatter over gloo on CPU tensors without rendering (no GPU needed).
+
 A step is one render of the README's 720x720 Cornell box (aa_iter=1, ref_iter=4,
 ind_rays=75, shadowSamples=50; main.cu:626-636) at the workload's gl_iter, with
 the scene, LTC tables, RNG states and framebuffer resident in HBM.  With N>1 the
@@ -89,7 +94,7 @@ def config5(args, torch, crt):
              the number of color() calls adaptive anti-aliasing makes per pixel, 4 at aa_iter 1 (it does not
              depend on gl_iter as long as gl_iter >= 1: the GI noise makes every colour comparison fail);
       rate   what one rank of eight launches -- crt_render_shard(rank 0 of 8), 64 800 pixels in interleaved 8x8
-             tiles -- timed over its first --c5-rounds pipeline rounds (CRT_WF_MAX_ROUNDS), with the GPU as full as
+             tiles -- timed over its first --c5-rounds pipeline rounds (crt_set_round_limit), with the GPU as full as
              it is in the real job (the end of the frame, where few pixels are left, is not in the sample).
     Reported: the rate in Msamples/s, and work / 8 / rate as the time eight GPUs would need."""
     dev = torch.device("cuda", 0)
@@ -111,24 +116,25 @@ def config5(args, torch, crt):
     calls_ratio = points[(4, 1)]["shade_points"] / points[(1, 1)]["shade_points"]
     frame_points = points[(1, 3)]["shade_points"] * calls_ratio
     st = crt.make_settings(nx=nx, ny=ny, aa_iter=4, gl_iter=3)
-    os.environ["CRT_WF_MAX_ROUNDS"] = str(args.c5_rounds)
-    try:
-        with crt.Context(0) as ctx:
-            ctx.upload(crt.cornell_box(50))
-            ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
-            n = crt.shard_tiles_max(nx, ny, 8) * 64 * 4
-            compact = torch.empty(n, dtype=torch.float32, device=dev)
-            ctx.reserve_workspace(st, 0, 8)
-            torch.cuda.synchronize(dev)
-            print(f"# sample: rank 0 of 8, {args.c5_rounds} rounds ...", file=sys.stderr, flush=True)
-            t0 = time.perf_counter()
-            ctx.render_shard(st, 0, 8, compact.data_ptr(), stream.cuda_stream)  # unfinished on purpose
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t0
-            done = int(ctx.stats(st).shade_points)
-            print(f"# sample: {done} shaded points in {dt:.2f} s", file=sys.stderr, flush=True)
-    finally:
-        del os.environ["CRT_WF_MAX_ROUNDS"]
+    with crt.Context(0) as ctx:
+        ctx.upload(crt.cornell_box(50))
+        ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
+        n = crt.shard_tiles_max(nx, ny, 8) * 64 * 4
+        compact = torch.empty(n, dtype=torch.float32, device=dev)
+        ctx.reserve_workspace(st, 0, 8)
+        ctx.set_round_limit(args.c5_rounds)  # this context only; the call below reports the frame as cut short
+        torch.cuda.synchronize(dev)
+        print(f"# sample: rank 0 of 8, {args.c5_rounds} rounds ...", file=sys.stderr, flush=True)
+        t0 = time.perf_counter()
+        try:
+            ctx.render_shard(st, 0, 8, compact.data_ptr(), stream.cuda_stream)
+        except crt.CrtError as err:
+            if err.code != crt.abi.CRT_ERR_TRUNCATED:
+                raise
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        done = int(ctx.stats(st).shade_points)
+        print(f"# sample: {done} shaded points in {dt:.2f} s", file=sys.stderr, flush=True)
     rate = done / dt
     est_s = frame_points / 8 / rate
     print(json.dumps({
@@ -147,6 +153,65 @@ def config5(args, torch, crt):
     }), flush=True)
 
 
+def launch_ranks(n):
+    """Re-runs this command line as n ranks under torch.distributed.run and returns their exit status.
+    The parent has made no HIP call, so the children are the only processes on the GPUs."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver shares device memory through dmabuf only
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world, rank):
+    """The N-rank plumbing without a GPU: gloo process group, every rank fills its compact shard with a pattern
+    keyed by global pixel index, the timed steps are gather + scatter, rank 0 checks the reassembled frame."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cudaraytracer_amd import distributed as shard
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    nx, ny = args.nx, args.ny
+    idx = shard.compact_pixel_index(nx, ny, rank, world)
+    compact = np.zeros((idx.size, 4), np.float32)
+    compact[idx >= 0] = (idx[idx >= 0, None] * 4 + np.arange(4)[None, :]).astype(np.float32)
+    compact = torch.from_numpy(compact.reshape(-1))
+    fb = None
+    for _ in range(args.warmup):
+        fb = shard.gather_image(compact, nx, ny)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fb = shard.gather_image(compact, nx, ny)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        want = np.arange(nx * ny * 4, dtype=np.float32).reshape(ny, nx, 4)
+        ok = fb is not None and np.array_equal(fb.numpy(), want)
+        print(json.dumps({"metric": "dry run: gather + scatter of the interleaved-tile shards over gloo, nothing rendered",
+                          "dry_run": True, "value": None, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "frame_ok": bool(ok),
+                          "config": {"workload": f"{nx}x{ny} pattern image", "sharding": "interleaved 8x8 tiles, tile % n_gpus"}}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if rank != 0 or ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,7 +228,17 @@ def main():
                     help="kernels behind crt_render: auto = wavefront pipeline where it applies")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-rows", action="store_true", help="skip the extra gl0/gl2 README rows at N=1")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher, process group (gloo) and gather/scatter only, on CPU tensors: no GPU, no render")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+
+    # N > 1 without a rank environment: start the ranks (before torch or HIP are touched in this process)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+    if args.dry_run:
+        raise SystemExit(dry_run(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))))
 
     import torch
     import torch.distributed as dist
@@ -175,8 +250,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

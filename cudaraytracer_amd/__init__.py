@@ -61,6 +61,7 @@ def lib():
             "crt_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
             "crt_set_trace_mode": (C.c_int, [C.c_void_p, C.c_int]),
             "crt_set_workspace_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
+            "crt_set_round_limit": (C.c_int, [C.c_void_p, C.c_uint32]),
             "crt_reserve_workspace": (C.c_int, [C.c_void_p, P(abi.crt_settings), C.c_uint32, C.c_uint32]),
             "crt_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
             "crt_get_kernel_times": (C.c_int, [C.c_void_p, P(C.c_double), P(C.c_uint64)]),
@@ -90,7 +91,7 @@ ABI_SYMBOLS = (
     "crt_rng_export", "crt_render", "crt_render_static", "crt_render_partial", "crt_render_shard", "crt_shard_tiles",
     "crt_shard_tiles_max", "crt_scatter_shards", "crt_stats_since_init", "crt_selftest_rcp", "crt_set_pipeline",
     "crt_set_trace_mode",
-    "crt_set_workspace_limit", "crt_reserve_workspace", "crt_set_audit", "crt_audit_result", "crt_set_timing",
+    "crt_set_workspace_limit", "crt_set_round_limit", "crt_reserve_workspace", "crt_set_audit", "crt_audit_result", "crt_set_timing",
     "crt_get_kernel_times", "crt_fb_alloc", "crt_fb_free",
     "crt_fb_download", "crt_write_hdr", "crt_encode_hdr", "crt_to_rgba8", "crt_write_ppm")
 
@@ -197,6 +198,11 @@ class Context:
 
     def set_workspace_limit(self, nbytes):
         self._check(lib().crt_set_workspace_limit(self._h, nbytes), "crt_set_workspace_limit")
+
+    def set_round_limit(self, rounds):
+        """Measuring aid: wavefront frames stop after `rounds` rounds (0 = no limit); a frame cut short raises
+        CrtError with code abi.CRT_ERR_TRUNCATED."""
+        self._check(lib().crt_set_round_limit(self._h, rounds), "crt_set_round_limit")
 
     KERNELS = ("trace", "filter", "resolve", "shade", "sum")
 

@@ -10,6 +10,7 @@ CRT_ERR_NO_SCENE = -3
 CRT_ERR_NO_RNG = -4
 CRT_ERR_UNSUPPORTED = -5
 CRT_ERR_IO = -6
+CRT_ERR_TRUNCATED = -7
 
 CRT_MAX_GEOMETRY = 64
 CRT_MAX_LIGHTS = 8

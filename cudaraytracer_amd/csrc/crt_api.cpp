@@ -24,6 +24,13 @@ extern "C" const unsigned char crt_ltc_tables_blob_end[];
 #define CRT_STATIC_HEAD_WORDS 64u
 static __device__ __align__(256) uint32_t scratch[CRT_STATIC_HEAD_WORDS + 2u * CRT_STATIC_MAX_PIXELS];
 static uint32_t* g_scratch_ptr[64] = {nullptr}; // per device: device address of `scratch` there
+// Per device: an event recorded behind the latest crt_render_static launch there, and the stream that launch went
+// to.  A call on another stream (or from another context) first makes its stream wait for that event, so calls
+// that would have overlapped on the shared array run one after the other instead.  Created by crt_create (the
+// entry point itself allocates nothing); calls from two host threads at once still need the caller's own lock.
+static hipEvent_t g_static_done[64] = {nullptr};
+static void* g_static_stream[64] = {nullptr};
+static bool g_static_used[64] = {false};
 
 struct crt_ctx {
     int device = 0;
@@ -41,6 +48,7 @@ struct crt_ctx {
     int pipeline = CRT_PIPELINE_AUTO;
     int audit = 0;
     int trace_mode = CRT_TRACE_AUTO;
+    int coop_permille = -1; // CRT_COOP_PERMILLE as read by crt_create (tools/mix_sweep.sh); -1: by launch size
     size_t workspace_limit = (size_t)32 << 30;
     crt::WfWorkspace wf;
 };
@@ -115,13 +123,13 @@ crt::RenderArgs base_args(crt_ctx* ctx, const crt_settings* st, float* out) {
 // Share (per mille) of this launch's work units, most expensive first, that go through the cooperative
 // trace kernel.  Measured at 720x720 gl_iter 1 (trace kernel, ms): 64 800 pixels, an eighth of the frame:
 // all cooperative 1.8, none 6.7; 129 600 pixels: all 3.3, 15-60 % 3.8, 6 % 4.1, none 7.1; 259 200 pixels: 6 % 4.8,
-// 15 % 4.9, all 6.4, none 7.7; the full frame: none 9.0, 3 % 8.9, all 12.4.  The environment variable is for such
-// measurements (tools/mix_sweep.sh).
+// 15 % 4.9, all 6.4, none 7.7; the full frame: none 9.0, 3 % 8.9, all 12.4.  The environment variable
+// CRT_COOP_PERMILLE, read once by crt_create, is for such measurements (tools/mix_sweep.sh); it changes speed only.
 uint32_t pick_cooperative(const crt_ctx* ctx, const crt::RenderArgs& a) {
     if (a.gl_iter == 0) return 0u;
     if (ctx->trace_mode == CRT_TRACE_COOPERATIVE) return 1000u;
     if (ctx->trace_mode == CRT_TRACE_PER_PIXEL) return 0u;
-    if (const char* env = getenv("CRT_COOP_PERMILLE")) return (uint32_t)atoi(env) > 1000u ? 1000u : (uint32_t)atoi(env);
+    if (ctx->coop_permille >= 0) return (uint32_t)ctx->coop_permille > 1000u ? 1000u : (uint32_t)ctx->coop_permille;
     const uint64_t pixels = (uint64_t)a.n_units * 64u;
     return pixels < 200000ull ? 1000u : pixels < 400000ull ? 60u : 0u;
 }
@@ -147,9 +155,12 @@ int run_render(crt_ctx* ctx, const crt::RenderArgs& args, hipStream_t stream) {
         HIP_TRY(ctx, crt::launch_render(a, stream));
         return CRT_OK;
     }
-    bool overflow = false;
-    HIP_TRY(ctx, crt::launch_wavefront(a, ctx->wf, stream, &overflow));
-    if (overflow) return fail(ctx, CRT_ERR_HIP, "wavefront pipeline: a device queue overflowed");
+    bool overflow = false, truncated = false;
+    HIP_TRY(ctx, crt::launch_wavefront(a, ctx->wf, stream, &overflow, &truncated));
+    if (overflow) return fail(ctx, CRT_ERR_HIP, "wavefront pipeline: a device queue overflowed (in this frame or one left running before it)");
+    if (truncated)
+        return fail(ctx, CRT_ERR_TRUNCATED, "frame stopped after %u rounds (crt_set_round_limit): image unfinished, RNG states mid-tree",
+                    ctx->wf.max_rounds);
     return CRT_OK;
 }
 
@@ -165,6 +176,7 @@ int crt_create(crt_ctx** out, int device) {
     crt_ctx* ctx = new (std::nothrow) crt_ctx();
     if (!ctx) return CRT_ERR_INVALID;
     ctx->device = device;
+    if (const char* env = getenv("CRT_COOP_PERMILLE")) ctx->coop_permille = atoi(env) < 0 ? 0 : atoi(env);
     const size_t ltc_bytes = (size_t)(crt_ltc_tables_blob_end - crt_ltc_tables_blob);
     if (ltc_bytes != 2u * 64u * 64u * 4u * sizeof(float) || hipSetDevice(device) != hipSuccess ||
         hipMalloc((void**)&ctx->ltc_dev, ltc_bytes) != hipSuccess ||
@@ -183,6 +195,12 @@ int crt_create(crt_ctx** out, int device) {
             return CRT_ERR_HIP;
         }
         g_scratch_ptr[device] = ptr;
+    }
+    if (device < 64 && g_static_done[device] == nullptr &&
+        hipEventCreateWithFlags(&g_static_done[device], hipEventDisableTiming) != hipSuccess) {
+        g_static_done[device] = nullptr;
+        crt_destroy(ctx);
+        return CRT_ERR_HIP;
     }
     if (crt::prime_render_grid() != hipSuccess) {
         crt_destroy(ctx);
@@ -267,6 +285,8 @@ int crt_rng_export(crt_ctx* ctx, uint32_t* host_state6) {
     const size_t npix = (size_t)ctx->rng_nx * ctx->rng_ny;
     std::vector<uint32_t> planes(npix * 6);
     HIP_TRY(ctx, hipDeviceSynchronize());
+    if (crt::wavefront_collect_async(ctx->wf, true))
+        return fail(ctx, CRT_ERR_HIP, "wavefront pipeline: a device queue overflowed in an earlier frame");
     HIP_TRY(ctx, hipMemcpy(planes.data(), ctx->rng_dev, npix * 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (size_t p = 0; p < npix; ++p)
         for (int k = 0; k < 6; ++k) host_state6[p * 6 + k] = planes[(size_t)k * npix + p];
@@ -293,7 +313,8 @@ int crt_render_static(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void*
     if ((uint64_t)st->nx * st->ny > CRT_STATIC_MAX_PIXELS)
         return fail(ctx, CRT_ERR_UNSUPPORTED, "crt_render_static: %ux%u pixels exceed CRT_STATIC_MAX_PIXELS (%u)", st->nx,
                     st->ny, (unsigned)CRT_STATIC_MAX_PIXELS);
-    if (!ctx->scratch_ptr) return fail(ctx, CRT_ERR_HIP, "crt_render_static: no scratch address for device %d", ctx->device);
+    if (!ctx->scratch_ptr || ctx->device >= 64 || !g_static_done[ctx->device])
+        return fail(ctx, CRT_ERR_HIP, "crt_render_static: no scratch address for device %d", ctx->device);
     if ((rc = bind(ctx)) != CRT_OK) return rc;
     crt::RenderArgs a = base_args(ctx, st, fb_dev);
     a.mode = crt::MODE_FULL;
@@ -306,8 +327,14 @@ int crt_render_static(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void*
     a.wave_tallies = reinterpret_cast<unsigned long long*>(sp + 16);
     a.counters = sp + CRT_STATIC_HEAD_WORDS;
     a.audit = 0u;
+    // the previous call on this GPU may still be using the array on another stream: queue behind it
+    const int dv = ctx->device;
+    if (g_static_used[dv] && g_static_stream[dv] != stream) HIP_TRY(ctx, hipStreamWaitEvent((hipStream_t)stream, g_static_done[dv], 0));
     HIP_TRY(ctx, hipMemsetAsync(sp, 0, (CRT_STATIC_HEAD_WORDS + 2u * npix) * sizeof(uint32_t), (hipStream_t)stream));
     HIP_TRY(ctx, crt::launch_render(a, (hipStream_t)stream));
+    HIP_TRY(ctx, hipEventRecord(g_static_done[dv], (hipStream_t)stream));
+    g_static_stream[dv] = stream;
+    g_static_used[dv] = true;
     return CRT_OK;
 }
 
@@ -394,6 +421,8 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out) {
     const size_t npix = (size_t)ctx->rng_nx * ctx->rng_ny;
     std::vector<uint32_t> d_now(npix), d_init(npix), cnt(npix * 2);
     HIP_TRY(ctx, hipDeviceSynchronize());
+    if (crt::wavefront_collect_async(ctx->wf, true))
+        return fail(ctx, CRT_ERR_HIP, "wavefront pipeline: a device queue overflowed in an earlier frame");
     HIP_TRY(ctx, hipMemcpy(d_now.data(), ctx->rng_dev + 5 * npix, npix * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(d_init.data(), ctx->rng_init_d, npix * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(cnt.data(), ctx->counters_dev, npix * 8, hipMemcpyDeviceToHost));
@@ -481,9 +510,21 @@ int crt_reserve_workspace(crt_ctx* ctx, const crt_settings* st, uint32_t rank, u
     a.rank = rank;
     a.world = world;
     a.n_units = world == 1 ? a.tiles_x * a.tiles_y : crt_shard_tiles(st->nx, st->ny, rank, world);
-    if (!crt::wavefront_supports(a)) return CRT_OK;
-    a.cooperative = pick_cooperative(ctx, a);
-    HIP_TRY(ctx, crt::wavefront_reserve(ctx->wf, a, ctx->scene_host.n_lights, ctx->workspace_limit));
+    a.cooperative = pick_cooperative(ctx, a); // before the check: the cooperative kernel needs more record slack
+    if (!crt::wavefront_supports(a)) return CRT_OK; // crt_render takes the persistent kernel (or refuses, if told to use the pipeline)
+    const hipError_t reserved = crt::wavefront_reserve(ctx->wf, a, ctx->scene_host.n_lights, ctx->workspace_limit);
+    if (reserved != hipSuccess) {
+        (void)hipGetLastError();
+        // as in crt_render: without a workspace the default configuration renders with the persistent kernel
+        if (ctx->pipeline == CRT_PIPELINE_WAVEFRONT)
+            return fail(ctx, CRT_ERR_HIP, "wavefront workspace: %s", hipGetErrorString(reserved));
+    }
+    return CRT_OK;
+}
+
+int crt_set_round_limit(crt_ctx* ctx, uint32_t rounds) {
+    if (!ctx) return CRT_ERR_INVALID;
+    ctx->wf.max_rounds = rounds;
     return CRT_OK;
 }
 

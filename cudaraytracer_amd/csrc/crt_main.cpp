@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
             std::printf("HIP initialized on %d GPU%s.\n", gpus, gpus == 1 ? "" : "s");
             renderer.randomInit(s.nx, s.ny, seed);
             renderer.setScene(box.camera, box.world, box.lights);
+            renderer.reserve(s.nx, s.ny); // the frame is allocated inside "Create World" (main.cu:699-700)
             auto t1 = clock::now();
             printTime("Create World", std::chrono::duration<double, std::milli>(t1 - t0).count());
             fb = renderer.render(s);
@@ -85,6 +86,7 @@ int main(int argc, char** argv) {
             std::printf("HIP initialized.\n");
             renderer.randomInit(s.nx, s.ny, seed);
             renderer.setScene(box.camera, box.world, box.lights);
+            renderer.reserve(s.nx, s.ny); // the frame is allocated inside "Create World" (main.cu:699-700)
             auto t1 = clock::now();
             printTime("Create World", std::chrono::duration<double, std::milli>(t1 - t0).count());
             fb = renderer.render(s); // returns after the device finished

@@ -80,6 +80,13 @@ struct WfWorkspace {
     void* join_event = nullptr;
     size_t bytes = 0;
     uint64_t frames_redone = 0;     // frames rendered a second time because the ray queue overflowed
+    // frames that were left running on their stream (one round, nothing that can overflow): their counter copies land
+    // in the ring slots of `async_pending` (bit k = slot k); wavefront_collect_async reads the flags once they have
+    uint32_t async_pending = 0, async_next = 0;
+    bool async_error = false;       // one of those frames raised a device flag (reported by the next call that looks)
+    void* last_stream = nullptr;    // stream of the last launch: a launch on another one is ordered behind it
+    // measuring aid (crt_set_round_limit): stop a frame after this many rounds; 0 = no limit
+    uint32_t max_rounds = 0;
     // optional per-kernel timing with HIP events on the launch stream (crt_set_timing)
     bool timing = false;
     void* timer = nullptr;   // event pool, owned by crt_wavefront.hip
@@ -111,7 +118,11 @@ void wavefront_release(WfWorkspace& ws);
 // overflow the ray queue (gl_iter 0 at aa_iter <= 1), which are left running on `stream`.  A frame whose
 // ray queue overflowed is rendered again from the saved generator states with launches sized for the worst
 // case.  *overflow is set when a capacity check on the device failed for good.
-hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow);
+// *truncated is set when the round limit (WfWorkspace::max_rounds) ended the frame with pixels unfinished.
+hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow, bool* truncated);
+// Looks at the counter copies of frames that were left running: with `wait` the call waits for them, without
+// it takes those that have landed.  Returns true (once) if one of them had raised a device flag.
+bool wavefront_collect_async(WfWorkspace& ws, bool wait);
 
 void launch_random_init(uint32_t npix, uint64_t seed, uint32_t* state, hipStream_t stream);
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream);

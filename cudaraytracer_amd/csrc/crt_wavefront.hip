@@ -2401,11 +2401,32 @@ void wavefront_release(WfWorkspace& ws) {
     (void)hipFree(ws.unit_cost);
     (void)hipFree(ws.unit_order);
     (void)hipHostFree(ws.unit_host);
-    const bool timing = ws.timing;
+    const bool timing = ws.timing, async_error = ws.async_error;
     const uint64_t redone = ws.frames_redone;
+    const uint32_t max_rounds = ws.max_rounds;
     ws = WfWorkspace();
     ws.timing = timing;
     ws.frames_redone = redone;
+    ws.async_error = async_error;
+    ws.max_rounds = max_rounds;
+}
+
+bool wavefront_collect_async(WfWorkspace& ws, bool wait) {
+    hipEvent_t* ev = static_cast<hipEvent_t*>(ws.round_events);
+    for (uint32_t k = 0; k < WF_CTR_RING && ev && ws.ctrs_host; ++k) {
+        if (!((ws.async_pending >> k) & 1u)) continue;
+        const hipError_t e = wait ? hipEventSynchronize(ev[k]) : hipEventQuery(ev[k]);
+        if (e == hipErrorNotReady) {
+            (void)hipGetLastError();
+            continue;
+        }
+        const uint32_t* host = ws.ctrs_host + (size_t)k * WF_CTR_COUNT;
+        if (e != hipSuccess || host[WF_CTR_ERROR] != 0u || host[WF_CTR_QOVERFLOW] != 0u) ws.async_error = true;
+        ws.async_pending &= ~(1u << k);
+    }
+    const bool bad = ws.async_error;
+    ws.async_error = false;
+    return bad;
 }
 
 hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n_lights, size_t budget_bytes) {
@@ -2432,6 +2453,7 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
         return hipSuccess;
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return e;
+    if (wavefront_collect_async(ws, true)) ws.async_error = true; // kept across the release for the next call that looks
     wavefront_release(ws);
     // + every trace wave's two partly used chunks; a multiple of the chunk size so that both streams stay aligned
     const uint32_t trace_waves = args.cooperative ? args.n_units * kCoopSplit : args.n_units;
@@ -2549,10 +2571,9 @@ hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const G
     if (e != hipSuccess) return e;
     flags_out[0] = flags_out[1] = 0u;
     const uint64_t rays_per_record = args.max_shadow_rays ? args.max_shadow_rays : 1u;
-    // Measuring aid (bench.py --workload c5): stop after this many rounds, leaving the frame unfinished, to time
-    // the steady state of a launch whose whole frame takes an hour.  Never set it when the image matters.
-    uint32_t max_rounds = 0xffffffffu;
-    if (const char* env = getenv("CRT_WF_MAX_ROUNDS")) max_rounds = (uint32_t)atoi(env) > 0 ? (uint32_t)atoi(env) : 1u;
+    // Measuring aid (crt_set_round_limit; bench.py --workload c5): stop after this many rounds to time the steady
+    // state of a launch whose whole frame takes an hour.  The caller reports a frame cut short as such.
+    const uint32_t max_rounds = ws.max_rounds ? ws.max_rounds : 0xffffffffu;
     uint32_t first = 1u;
     for (uint32_t round = 0;; ++round) {
         uint32_t* host = ws.ctrs_host + (size_t)(round % WF_CTR_RING) * WF_CTR_COUNT;
@@ -2616,7 +2637,23 @@ hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const G
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         first = 0u;
-        if (leave_running) return hipSuccess; // one round, nothing that can overflow: nothing to wait for
+        if (leave_running) {
+            // one round, nothing that can overflow: nothing to wait for.  The round's flags still go to the host, into
+            // the next slot of the ring, and are looked at by a later call (wavefront_collect_async).
+            const uint32_t k = ws.async_next % WF_CTR_RING;
+            if ((ws.async_pending >> k) & 1u) { // the frame four calls back: long finished
+                e = hipEventSynchronize(ev[k]);
+                if (e != hipSuccess) return e;
+                (void)wavefront_collect_async(ws, false);
+                if ((ws.async_pending >> k) & 1u) return hipErrorUnknown;
+            }
+            e = hipMemcpyAsync(ws.ctrs_host + (size_t)k * WF_CTR_COUNT, ws.ctrs, WF_CTR_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipEventRecord(ev[k], stream);
+            if (e != hipSuccess) return e;
+            ws.async_pending |= 1u << k;
+            ws.async_next = k + 1u;
+            return hipSuccess;
+        }
         if (round + 1u >= max_rounds) break;
         if (safe) {
             if (host[WF_CTR_ACTIVE] == 0u) break;
@@ -2645,8 +2682,9 @@ hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const G
 
 } // namespace
 
-hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow) {
+hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow, bool* truncated) {
     *overflow = false;
+    *truncated = false;
     if (args.n_units == 0) return hipSuccess;
     if (ws.timing && !ws.timer) ws.timer = new EventTimer();
     EventTimer* timer = ws.timing ? static_cast<EventTimer*>(ws.timer) : nullptr;
@@ -2662,6 +2700,14 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     }
     const uint32_t cus = (uint32_t)g_resident_cus[dev];
     if (ws.npix != args.nx * args.ny) return hipErrorInvalidValue; // wavefront_reserve was given another image
+    // Frames left running on another stream share this context's workspace, counters and generator states: this
+    // launch is ordered behind the latest of them.  (Frames that returned after their last round have been waited for.)
+    if (ws.async_pending != 0u && ws.last_stream != (void*)stream) {
+        const uint32_t latest = (ws.async_next + WF_CTR_RING - 1u) % WF_CTR_RING;
+        e = hipStreamWaitEvent(stream, static_cast<hipEvent_t*>(ws.round_events)[latest], 0);
+        if (e != hipSuccess) return e;
+    }
+    ws.last_stream = (void*)stream;
 
     WfArgs w;
     w.r = args;
@@ -2803,10 +2849,13 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
             e = hipMemcpyAsync(ws.backup + 8u * npix, args.wave_tallies, 8u * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
         if (e != hipSuccess) return e;
     }
-    const bool leave_running = ws.single_round && !can_overflow && !timer && !args.audit;
+    const bool leave_running = ws.single_round && !can_overflow && !timer && !args.audit && ws.max_rounds == 0u;
+    // flags of earlier frames that were left running: all of them before a frame that uses the ring for its rounds
+    if (wavefront_collect_async(ws, !leave_running)) *overflow = true;
     uint32_t flags[2] = {0u, 0u};
     e = run_frame(args, ws, w, g, n_coop, false, leave_running, stream, timer, flags);
     if (e != hipSuccess) return e;
+    if (!leave_running && ws.max_rounds != 0u && ws.ctrs_host[WF_CTR_ACTIVE] != 0u) *truncated = true;
     if (flags[0] == 0u && flags[1] != 0u && can_overflow) {
         // rays were dropped: the same frame again from where it started, with launches that cannot overflow
         e = hipMemcpyAsync(args.rng, ws.backup, npix * 6u * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);

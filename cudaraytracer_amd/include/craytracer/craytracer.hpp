@@ -122,6 +122,8 @@ struct CornellBox {
 // upload scene, seed the per-pixel RNG, render, read back, write file.hdr.
 class Renderer {
     crt_ctx* _ctx = nullptr;
+    float* _fb = nullptr; // device frame of render(), kept from call to call
+    size_t _fb_floats = 0;
     static void check(int rc, crt_ctx* ctx, const char* what) {
         if (rc != CRT_OK)
             throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " +
@@ -130,7 +132,10 @@ class Renderer {
 
 public:
     explicit Renderer(int device = 0) { check(crt_create(&_ctx, device), nullptr, "crt_create"); }
-    ~Renderer() { crt_destroy(_ctx); }
+    ~Renderer() {
+        if (_fb) crt_fb_free(_ctx, _fb);
+        crt_destroy(_ctx);
+    }
     Renderer(const Renderer&) = delete;
     Renderer& operator=(const Renderer&) = delete;
     crt_ctx* handle() const { return _ctx; }
@@ -143,31 +148,37 @@ public:
     void randomInit(unsigned int nx, unsigned int ny, unsigned long long seed) {
         check(crt_rng_init(_ctx, nx, ny, seed, nullptr), _ctx, "crt_rng_init");
     }
+    // Allocates render()'s device frame for an nx x ny image (render() does it on first use; the reference
+    // allocates its frame before the render timer starts, main.cu:699-700).  Pixels a progressive walk never
+    // reaches read as 0.
+    void reserve(unsigned int nx, unsigned int ny) {
+        const size_t n = static_cast<size_t>(nx) * ny * 4;
+        if (_fb && _fb_floats == n) return;
+        if (_fb) crt_fb_free(_ctx, _fb);
+        _fb = nullptr;
+        _fb_floats = 0;
+        check(crt_fb_alloc(_ctx, n, &_fb), _ctx, "crt_fb_alloc");
+        _fb_floats = n;
+    }
     // Renders into a host RGBA float image (nx*ny*4), honouring renderAllAtOnce / blocksPerDraw.
     std::vector<float> render(const RenderSettings& s) {
         crt_settings st = s.flatten();
         const size_t n = static_cast<size_t>(s.nx) * s.ny * 4;
-        float* dev = nullptr;
-        check(crt_fb_alloc(_ctx, n, &dev), _ctx, "crt_fb_alloc");
+        reserve(s.nx, s.ny);
+        float* dev = _fb;
         std::vector<float> host(n);
-        try {
-            if (s.renderAllAtOnce) {
-                check(crt_render(_ctx, &st, dev, nullptr), _ctx, "crt_render");
-            } else {
-                // the window arithmetic below divides by the block shape; the ABI would refuse these, too
-                if (s.tx == 0 || s.ty == 0 || s.blocksPerDraw == 0)
-                    throw std::invalid_argument("tx, ty and blocksPerDraw must be positive");
-                const unsigned int blocksX = s.nx / s.tx + 1, blocksY = s.ny / s.ty + 1;
-                const unsigned int totalTiles = blocksX * blocksY;
-                for (unsigned int tileIndex = 0; tileIndex < totalTiles; tileIndex += s.blocksPerDraw)
-                    check(crt_render_partial(_ctx, &st, tileIndex, dev, nullptr), _ctx, "crt_render_partial");
-            }
-            check(crt_fb_download(_ctx, dev, host.data(), n, nullptr), _ctx, "crt_fb_download");
-        } catch (...) {
-            crt_fb_free(_ctx, dev);
-            throw;
+        if (s.renderAllAtOnce) {
+            check(crt_render(_ctx, &st, dev, nullptr), _ctx, "crt_render");
+        } else {
+            // the window arithmetic below divides by the block shape; the ABI would refuse these, too
+            if (s.tx == 0 || s.ty == 0 || s.blocksPerDraw == 0)
+                throw std::invalid_argument("tx, ty and blocksPerDraw must be positive");
+            const unsigned int blocksX = s.nx / s.tx + 1, blocksY = s.ny / s.ty + 1;
+            const unsigned int totalTiles = blocksX * blocksY;
+            for (unsigned int tileIndex = 0; tileIndex < totalTiles; tileIndex += s.blocksPerDraw)
+                check(crt_render_partial(_ctx, &st, tileIndex, dev, nullptr), _ctx, "crt_render_partial");
         }
-        crt_fb_free(_ctx, dev);
+        check(crt_fb_download(_ctx, dev, host.data(), n, nullptr), _ctx, "crt_fb_download");
         return host;
     }
 };

@@ -28,6 +28,11 @@ class MultiGpuRenderer {
     std::vector<crt_ctx*> _ctx;
     std::vector<ncclComm_t> _comms;
     std::vector<hipStream_t> _streams;
+    // device buffers of render(), kept from call to call and re-made only when the image size changes: every
+    // rank's compact shard, and on the first GPU the gathered shards and the row-major frame
+    std::vector<float*> _compact;
+    float *_gathered = nullptr, *_fb = nullptr;
+    unsigned int _buf_nx = 0, _buf_ny = 0;
 
     static void check(int rc, crt_ctx* ctx, const char* what) {
         if (rc != CRT_OK)
@@ -92,6 +97,26 @@ public:
         for (size_t r = 0; r < _ctx.size(); ++r) check(crt_rng_init(_ctx[r], nx, ny, seed, _streams[r]), _ctx[r], "crt_rng_init");
     }
 
+    // Allocates render()'s device buffers for an nx x ny image (render() does it on first use; calling it
+    // beforehand keeps the allocation out of a timed render).
+    void reserve(unsigned int nx, unsigned int ny) {
+        if (_buf_nx == nx && _buf_ny == ny && _fb) return;
+        free_buffers();
+        const uint32_t world = static_cast<uint32_t>(_ctx.size());
+        const size_t shard_floats = static_cast<size_t>(crt_shard_tiles_max(nx, ny, world)) * 256u;
+        _compact.assign(world, nullptr);
+        try {
+            for (uint32_t r = 0; r < world; ++r) check(crt_fb_alloc(_ctx[r], shard_floats, &_compact[r]), _ctx[r], "crt_fb_alloc");
+            check(crt_fb_alloc(_ctx[0], shard_floats * world, &_gathered), _ctx[0], "crt_fb_alloc");
+            check(crt_fb_alloc(_ctx[0], static_cast<size_t>(nx) * ny * 4, &_fb), _ctx[0], "crt_fb_alloc");
+        } catch (...) {
+            free_buffers();
+            throw;
+        }
+        _buf_nx = nx;
+        _buf_ny = ny;
+    }
+
     // Renders into a host RGBA float image (nx*ny*4).
     std::vector<float> render(const RenderSettings& s) {
         if (!s.renderAllAtOnce) throw std::invalid_argument("the progressive walk is a single-GPU mode");
@@ -99,46 +124,40 @@ public:
         const uint32_t world = static_cast<uint32_t>(_ctx.size());
         const size_t shard_floats = static_cast<size_t>(crt_shard_tiles_max(s.nx, s.ny, world)) * 256u;
         const size_t n = static_cast<size_t>(s.nx) * s.ny * 4;
-        std::vector<float*> compact(world, nullptr);
-        float *gathered = nullptr, *fb = nullptr;
         std::vector<float> host(n);
-        auto free_all = [&] {
-            for (uint32_t r = 0; r < world; ++r)
-                if (compact[r]) crt_fb_free(_ctx[r], compact[r]);
-            if (gathered) crt_fb_free(_ctx[0], gathered);
-            if (fb) crt_fb_free(_ctx[0], fb);
-        };
-        try {
-            for (uint32_t r = 0; r < world; ++r) check(crt_fb_alloc(_ctx[r], shard_floats, &compact[r]), _ctx[r], "crt_fb_alloc");
-            check(crt_fb_alloc(_ctx[0], shard_floats * world, &gathered), _ctx[0], "crt_fb_alloc");
-            check(crt_fb_alloc(_ctx[0], n, &fb), _ctx[0], "crt_fb_alloc");
-            // every rank renders its tiles
-            for_each_rank([&](size_t r) {
-                check(crt_render_shard(_ctx[r], &st, static_cast<uint32_t>(r), world, compact[r], _streams[r]), _ctx[r],
-                      "crt_render_shard");
-            });
-            // one gather to rank 0, queued behind each rank's render on its stream
-            nccl(ncclGroupStart(), "ncclGroupStart");
-            for (uint32_t r = 0; r < world; ++r)
-                nccl(ncclGather(compact[r], r == 0 ? gathered : nullptr, shard_floats, ncclFloat, 0, _comms[r], _streams[r]),
-                     "ncclGather");
-            nccl(ncclGroupEnd(), "ncclGroupEnd");
-            check(crt_scatter_shards(_ctx[0], s.nx, s.ny, world, gathered, fb, _streams[0]), _ctx[0], "crt_scatter_shards");
-            check(crt_fb_download(_ctx[0], fb, host.data(), n, _streams[0]), _ctx[0], "crt_fb_download");
-            for (uint32_t r = 1; r < world; ++r) { // the senders' part of the gather
-                hip(hipSetDevice(_devices[r]), "hipSetDevice");
-                hip(hipStreamSynchronize(_streams[r]), "hipStreamSynchronize");
-            }
-        } catch (...) {
-            free_all();
-            throw;
+        reserve(s.nx, s.ny);
+        // every rank renders its tiles
+        for_each_rank([&](size_t r) {
+            check(crt_render_shard(_ctx[r], &st, static_cast<uint32_t>(r), world, _compact[r], _streams[r]), _ctx[r],
+                  "crt_render_shard");
+        });
+        // one gather to rank 0, queued behind each rank's render on its stream
+        nccl(ncclGroupStart(), "ncclGroupStart");
+        for (uint32_t r = 0; r < world; ++r)
+            nccl(ncclGather(_compact[r], r == 0 ? _gathered : nullptr, shard_floats, ncclFloat, 0, _comms[r], _streams[r]),
+                 "ncclGather");
+        nccl(ncclGroupEnd(), "ncclGroupEnd");
+        check(crt_scatter_shards(_ctx[0], s.nx, s.ny, world, _gathered, _fb, _streams[0]), _ctx[0], "crt_scatter_shards");
+        check(crt_fb_download(_ctx[0], _fb, host.data(), n, _streams[0]), _ctx[0], "crt_fb_download");
+        for (uint32_t r = 1; r < world; ++r) { // the senders' part of the gather
+            hip(hipSetDevice(_devices[r]), "hipSetDevice");
+            hip(hipStreamSynchronize(_streams[r]), "hipStreamSynchronize");
         }
-        free_all();
         return host;
     }
 
 private:
+    void free_buffers() {
+        for (size_t r = 0; r < _compact.size(); ++r)
+            if (_compact[r] && r < _ctx.size() && _ctx[r]) crt_fb_free(_ctx[r], _compact[r]);
+        _compact.clear();
+        if (_gathered && !_ctx.empty() && _ctx[0]) crt_fb_free(_ctx[0], _gathered);
+        if (_fb && !_ctx.empty() && _ctx[0]) crt_fb_free(_ctx[0], _fb);
+        _gathered = _fb = nullptr;
+        _buf_nx = _buf_ny = 0;
+    }
     void release() {
+        free_buffers();
         for (ncclComm_t c : _comms)
             if (c) ncclCommDestroy(c);
         _comms.clear();

@@ -36,6 +36,7 @@ extern "C" {
 #define CRT_ERR_NO_RNG (-4)      /* render before crt_rng_init, or size mismatch */
 #define CRT_ERR_UNSUPPORTED (-5) /* setting outside the implemented range */
 #define CRT_ERR_IO (-6)          /* file could not be written */
+#define CRT_ERR_TRUNCATED (-7)   /* the frame was stopped by crt_set_round_limit before it was finished */
 
 /* ---- limits ------------------------------------------------------------- */
 #define CRT_MAX_GEOMETRY 64u /* primitives per GeometryList */
@@ -193,9 +194,11 @@ int crt_render(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void* stream
  * holds until the process ends; the call makes no hipMalloc/hipFree and no allocating library call (set-up
  * -- crt_create, crt_scene_upload, crt_rng_init -- has allocated what the context owns).  Images of more than
  * CRT_STATIC_MAX_PIXELS pixels are refused with CRT_ERR_UNSUPPORTED.  All calls on one GPU share that GPU's
- * array (the part a call uses is cleared on `stream` first): calls that overlap on one GPU -- two streams,
- * two contexts or two threads -- race on it, so keep them on one stream or serialise them.  The work
- * counters of these calls stay in the array and are not part of crt_stats_since_init. */
+ * array (the part a call uses is cleared on `stream` first).  A call on another stream or context than the
+ * previous one on that GPU is queued behind it (a per-device event, made by crt_create), so such calls run one
+ * after the other instead of overlapping on the array; calls made from two host threads at the same moment
+ * still race on that bookkeeping and need the caller's own lock.  The work counters of these calls stay in the
+ * array and are not part of crt_stats_since_init. */
 #define CRT_STATIC_MAX_PIXELS (1u << 20)
 int crt_render_static(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void* stream);
 /* Replaces one render_partial launch of the progressive loop (main.cu:349-368,
@@ -237,7 +240,9 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out);
  *   CRT_PIPELINE_WAVEFRONT   trace / filter / resolve / shade / sum kernels with records in device
  *                            memory, sized from device-side counters.  A frame of one round whose ray
  *                            queue cannot overflow (gl_iter 0 at aa_iter <= 1) is asynchronous on
- *                            `stream`; any other call returns after the image is complete (rounds are
+ *                            `stream` (its device-side capacity flags are read by the next call on the
+ *                            context that looks: a render, crt_rng_export, crt_stats_since_init; a render on
+ *                            another stream is ordered behind it); any other call returns after the image is complete (rounds are
  *                            queued back to back, the host waits for the last one, and a frame that
  *                            left more shadow rays undecided than the queue holds is rendered a second
  *                            time from its saved generator states)
@@ -283,6 +288,12 @@ int crt_reserve_workspace(crt_ctx* ctx, const crt_settings* st, uint32_t rank, u
 /* Upper bound in bytes of the wavefront pipeline's device workspace (default 32 GiB); a smaller
  * bound means more rounds per image, never a different image.  No counterpart in the reference. */
 int crt_set_workspace_limit(crt_ctx* ctx, size_t bytes);
+/* Measuring aid: wavefront frames of this context stop after `rounds` pipeline rounds (0, the default: no
+ * limit), to time the steady state of a launch whose whole frame takes an hour.  A frame that is cut short
+ * returns CRT_ERR_TRUNCATED: its image is unfinished and its RNG states are left in the middle of their trees
+ * (crt_rng_init before anything else is rendered).  Frames that finish within the limit return CRT_OK.  No
+ * counterpart in the reference. */
+int crt_set_round_limit(crt_ctx* ctx, uint32_t rounds);
 
 /* Device self-test: compares the kernels' fast correctly-rounded reciprocal with
  * the IEEE quotient 1.0f/x for all 2^32 float bit patterns.  Returns the number

@@ -2,7 +2,11 @@ import sys
 from pathlib import Path
 
 import pytest
-import torch  # noqa: F401  (first, so that the process ends up with one HIP runtime whichever test file runs alone)
+
+try:  # first, so that the process ends up with one HIP runtime whichever test file runs alone
+    import torch  # noqa: F401
+except ImportError:  # the CPU-only tests of the checker, the texture and the LTC clipping need no torch
+    torch = None
 
 ROOT = Path(__file__).resolve().parent.parent
 for p in (str(ROOT), str(ROOT / "tests")):
@@ -25,7 +29,7 @@ def oracle():
 def gpu_ctx(request):
     """One context per pipeline on cuda:0 shared by the GPU tests (fails loudly without the HIP library
     or a GPU).  "auto" is the default configuration: the wavefront kernels, with the cooperative trace
-    kernel for launches below 100 000 pixels; "per_pixel" forces the one-lane-per-pixel trace kernel."""
+    kernel for launches below 200 000 pixels; "per_pixel" forces the one-lane-per-pixel trace kernel."""
     import cudaraytracer_amd as crt
     from cudaraytracer_amd import abi
     ctx = crt.Context(0)

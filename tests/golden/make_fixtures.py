@@ -15,6 +15,12 @@ Outputs (data only -- decoded pixel statistics and one output image of the refer
                              function) and must come back byte for byte, or the script stops.
   render0.hdr                byte copy of renders/render0.hdr, the reference's own output for README
                              row 0; pins the byte format of the .hdr writer
+  ltc_tables_pin.json        SHA-256 of the 2 x 16384 float32 values of ltc_1 and ltc_2 as this script parses them
+                             from the reference's ltc.hpp (line by line, four literals a line -- not the way
+                             tools/extract_ltc.py reads them), plus a few spot values.  The product and the CPU
+                             checker both read cudaraytracer_amd/data/ltc_tables.f32, so a wrong extraction would
+                             be invisible to every GPU-against-checker comparison; tests/test_oracle_golden.py
+                             holds that file to these digests.
 """
 import hashlib
 import json
@@ -42,7 +48,42 @@ FILES = {
 BLOCKS = ("renders/render0.hdr", "renders/render1.hdr", "renders/render2.hdr", "file75.hdr")
 
 
+def ltc_pin():
+    """Parses ltc_1 / ltc_2 (ltc.hpp:24-4124, 4127-8227) line by line and returns their digests."""
+    lines = (REF / "ltc.hpp").read_text(errors="replace").splitlines()
+    starts = [k for k, ln in enumerate(lines) if ln.startswith("__device__ float ltc_")]
+    if len(starts) != 2:
+        raise SystemExit("ltc.hpp: expected two __device__ float tables")
+    tables = []
+    for k in starts:
+        vals = []
+        for ln in lines[k + 1:]:
+            t = ln.strip()
+            if t.startswith("};"):
+                break
+            if not t or t[0] == "#" or t.startswith("static const"):
+                continue
+            toks = [x.strip() for x in t.rstrip(",").split(",")]
+            if len(toks) != 4 or not all(x.endswith("f") for x in toks):
+                raise SystemExit(f"ltc.hpp: unexpected table line {ln!r}")
+            vals.extend(float(x[:-1]) for x in toks)
+        if len(vals) != 64 * 64 * 4:
+            raise SystemExit(f"ltc.hpp: table at line {k + 1} has {len(vals)} values")
+        tables.append(np.array(vals, dtype=np.float64).astype("<f4"))
+    t1, t2 = tables
+    both = np.concatenate([t1, t2])
+    return {"source": "ltc.hpp:24-4124 (ltc_1), ltc.hpp:4127-8227 (ltc_2); float32, row-major [y][x][channel]",
+            "floats_per_table": int(t1.size),
+            "ltc_1_sha256": hashlib.sha256(t1.tobytes()).hexdigest(),
+            "ltc_2_sha256": hashlib.sha256(t2.tobytes()).hexdigest(),
+            "both_sha256": hashlib.sha256(both.tobytes()).hexdigest(),
+            "ltc_1_first8": [float(x) for x in t1[:8]], "ltc_1_last4": [float(x) for x in t1[-4:]],
+            "ltc_2_first8": [float(x) for x in t2[:8]], "ltc_2_last4": [float(x) for x in t2[-4:]],
+            "sum_float64": [float(t1.astype(np.float64).sum()), float(t2.astype(np.float64).sum())]}
+
+
 def main():
+    (HERE / "ltc_tables_pin.json").write_text(json.dumps(ltc_pin(), indent=1))
     stats = {}
     for rel, note in FILES.items():
         raw = (REF / rel).read_bytes()

@@ -285,17 +285,23 @@ def test_full_size_gl1_properties(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("case", ["cornell_128_gl2", "cornell_256_aa3_gl1", "cornell_12_gl3", "cornell_4_aa4_gl2",
-                                  "cornell_6_aa4_gl3"])
+                                  "cornell_1x8_aa4_gl3", "cornell_1x8_aa4_gl3_s50", "cornell_6_aa4_gl3"])
 def test_frozen_frames(gpu_ctx, case):
     """Whole frames the CPU restatement needs minutes for, frozen as checksums by
     tests/golden/make_oracle_frames.py: every pixel, every end state and the work counters.  Two GI levels;
     adaptive anti-aliasing three levels deep over one GI level; and BASELINE's last configuration (aa_iter 4
-    over gl_iter 3 with ind_rays 75) as its two halves -- ind_rays 75 three levels deep, where the 128-entry
+    over gl_iter 3 with ind_rays 75): as its two halves -- ind_rays 75 three levels deep, where the 128-entry
     stack leaves 54 children at level 1 and 1 to 21 at level 2, and 340 color() calls per pixel over the
-    truncated tree -- and whole, in miniature: 36 pixels of 5.5e7 shaded points each.  A lane walks a pixel's
-    tree step by step, so the miniature takes the GPU several minutes however few its pixels are; it runs
-    only with CRT_LONG_TESTS=1 and in the default configuration."""
+    truncated tree -- and whole, at the configuration's own parameters (cornell_1x8_aa4_gl3_s50: 50 shadow
+    samples; cornell_1x8_aa4_gl3: 4), on the eight pixels of a 1 x 8 image, 5.5e7 shaded points each.  A pixel's
+    tree is walked step by step, so how long such a frame takes is set by the pixels one wave walks, not by
+    their number: in the 1 x 8 image every wave of the cooperative trace kernel owns one pixel, and the default
+    configuration renders it in well under a minute.  The per-pixel kernel and the persistent kernel, one lane
+    per pixel, would take minutes; so would the 6 x 6 miniature (six pixels per wave), which runs only with
+    CRT_LONG_TESTS=1."""
     import os
+    if case.startswith("cornell_1x8") and gpu_ctx.pipeline_name != "auto":
+        pytest.skip("one lane per pixel: minutes of GPU time for 5.5e7 dependent steps (the default pipeline runs it)")
     if case == "cornell_6_aa4_gl3" and (os.environ.get("CRT_LONG_TESTS") != "1" or gpu_ctx.pipeline_name != "auto"):
         pytest.skip("minutes of GPU time: set CRT_LONG_TESTS=1 (default pipeline only)")
     import json
@@ -580,7 +586,7 @@ def test_glass_walk_inside_spheres_with_untrusted_quads(oracle, gpu_ctx, seed, a
 @pytest.mark.parametrize("n,aa,gl,ind,S,share", [(40, 1, 1, 75, 8, 350), (24, 2, 2, 7, 3, 500), (33, 1, 1, 9, 5, 1)])
 def test_mixed_trace_launch_matches_oracle(oracle, monkeypatch, n, aa, gl, ind, S, share):
     """A launch in which the most expensive units go through the cooperative trace kernel on a second stream
-    and the rest through the per-pixel kernel (what the default does between 100 000 and 400 000 pixels);
+    and the rest through the per-pixel kernel (what the default does between 200 000 and 400 000 pixels);
     CRT_COOP_PERMILLE forces that split on a small image."""
     from cudaraytracer_amd import abi
     monkeypatch.setenv("CRT_COOP_PERMILLE", str(share))

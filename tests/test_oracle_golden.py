@@ -7,6 +7,8 @@ What it is pinned to:
   * tests/golden/survey_anchors.json -- known-answer RNG values and seed-1234 images recorded from the
     reference's headers compiled for the host with stand-ins for what the image lacks: it corroborates, it is
     not the reference's own output.
+  * tests/golden/ltc_tables_pin.json -- digests of ltc_1 / ltc_2 as parsed from the reference's ltc.hpp: the
+    checker and the HIP library read the same cudaraytracer_amd/data/ltc_tables.f32, so that file is held to them.
 Bit-parity with real cuRAND output stays unpinned: no artefact of the reference records a seed.
 """
 import ctypes as C
@@ -22,6 +24,28 @@ from hdr_codec import decode_hdr, rgbe_to_float
 GOLD = Path(__file__).resolve().parent / "golden"
 ANCH = json.loads((GOLD / "survey_anchors.json").read_text())
 STATS = json.loads((GOLD / "reference_hdr_stats.json").read_text())
+
+
+def test_ltc_tables_are_the_reference_s(oracle):
+    """The LTC table file both sides load (and the copy embedded in libcrt_hip.so) against the digests
+    tests/golden/make_fixtures.py took from ltc.hpp:24-4124,4127-8227 with a parser of its own."""
+    import hashlib
+    import cudaraytracer_amd as crt
+    pin = json.loads((GOLD / "ltc_tables_pin.json").read_text())
+    n = pin["floats_per_table"]
+    assert n == 64 * 64 * 4
+    raw = oracle.LTC_PATH.read_bytes()
+    assert len(raw) == 2 * n * 4
+    assert hashlib.sha256(raw[:n * 4]).hexdigest() == pin["ltc_1_sha256"]
+    assert hashlib.sha256(raw[n * 4:]).hexdigest() == pin["ltc_2_sha256"]
+    assert hashlib.sha256(raw).hexdigest() == pin["both_sha256"]
+    t = np.frombuffer(raw, dtype="<f4")
+    assert t[:8].tolist() == pin["ltc_1_first8"] and t[n - 4:n].tolist() == pin["ltc_1_last4"]
+    assert t[n:n + 8].tolist() == pin["ltc_2_first8"] and t[-4:].tolist() == pin["ltc_2_last4"]
+    assert np.array_equal(oracle.ltc_tables(), t)
+    # the bytes the HIP library was linked with
+    blob = (C.c_ubyte * (2 * n * 4)).in_dll(crt.lib(), "crt_ltc_tables_blob")
+    assert hashlib.sha256(bytes(blob)).hexdigest() == pin["both_sha256"]
 
 
 def test_rng_known_answers(oracle):

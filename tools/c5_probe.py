@@ -12,7 +12,6 @@ import cudaraytracer_amd as crt  # noqa: E402
 
 world, rounds = int(sys.argv[1]), int(sys.argv[2])
 mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-os.environ["CRT_WF_MAX_ROUNDS"] = str(rounds)
 st = crt.make_settings(aa_iter=4, gl_iter=3)
 ctx = crt.Context(0)
 ctx.set_trace_mode(mode)
@@ -24,8 +23,13 @@ t0 = time.perf_counter()
 ctx.reserve_workspace(st, 0, world)
 print(f"workspace reserved in {time.perf_counter() - t0:.2f} s", flush=True)
 ctx.set_timing(True)
+ctx.set_round_limit(rounds)
 t0 = time.perf_counter()
-ctx.render_shard(st, 0, world, buf)
+try:
+    ctx.render_shard(st, 0, world, buf)
+except crt.CrtError as err:  # cut short on purpose
+    if err.code != crt.abi.CRT_ERR_TRUNCATED:
+        raise
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 k = {name: (round(ms, 1), int(cnt)) for name, (ms, cnt) in ctx.kernel_times().items()}
