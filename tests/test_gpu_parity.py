@@ -296,13 +296,13 @@ def test_frozen_frames(gpu_ctx, case):
     samples; cornell_1x8_aa4_gl3: 4), on the eight pixels of a 1 x 8 image, 5.5e7 shaded points each.  A pixel's
     tree is walked step by step, so how long such a frame takes is set by the pixels one wave walks, not by
     their number: in the 1 x 8 image every wave of the cooperative trace kernel owns one pixel, and the default
-    configuration renders it in well under a minute.  The per-pixel kernel and the persistent kernel, one lane
-    per pixel, would take minutes; so would the 6 x 6 miniature (six pixels per wave), which runs only with
-    CRT_LONG_TESTS=1."""
+    configuration renders it in a little over a minute (the 50-sample frame runs in every GPU test run).  The
+    per-pixel kernel and the persistent kernel, one lane per pixel, would take minutes; so would the 6 x 6
+    miniature (six pixels per wave), which runs only with CRT_LONG_TESTS=1, like the 4-sample 1 x 8 frame."""
     import os
     if case.startswith("cornell_1x8") and gpu_ctx.pipeline_name != "auto":
         pytest.skip("one lane per pixel: minutes of GPU time for 5.5e7 dependent steps (the default pipeline runs it)")
-    if case == "cornell_6_aa4_gl3" and (os.environ.get("CRT_LONG_TESTS") != "1" or gpu_ctx.pipeline_name != "auto"):
+    if case in ("cornell_6_aa4_gl3", "cornell_1x8_aa4_gl3") and (os.environ.get("CRT_LONG_TESTS") != "1" or gpu_ctx.pipeline_name != "auto"):
         pytest.skip("minutes of GPU time: set CRT_LONG_TESTS=1 (default pipeline only)")
     import json
     from pathlib import Path
