@@ -37,6 +37,28 @@ def algorithmic_flops(stats):
     return 300.0 * stats["shadow_samples"] + 1200.0 * stats["shade_points"] + 40.0 * stats["gi_children"]
 
 
+def kernel_flops(stats):
+    """The same model split by the kernel that does the work: the closest-hit query of a shaded point (450 of its
+    1200) and the generation of the GI children are the trace kernel's, the shadow samples the filter and resolve
+    kernels', AreaLight::calculateColor's LTC part (750) the shade kernel's; the sum kernel only adds."""
+    return {"trace": 450.0 * stats["shade_points"] + 40.0 * stats["gi_children"],
+            "filter+resolve": 300.0 * stats["shadow_samples"],
+            "shade": 750.0 * stats["shade_points"]}
+
+
+def per_kernel_roofline(ktimes, per_launch):
+    """{kernel: ms, model TFLOP/s and fraction of the packed FP32 peak} from per-frame kernel times and work."""
+    fl = kernel_flops(per_launch)
+    ms = {"trace": ktimes.get("trace", (0, 0))[0], "filter+resolve": ktimes.get("filter", (0, 0))[0] + ktimes.get("resolve", (0, 0))[0],
+          "shade": ktimes.get("shade", (0, 0))[0]}
+    out = {}
+    for k in fl:
+        if ms[k] > 0:
+            t = fl[k] / (ms[k] * 1e-3) / 1e12
+            out[k] = {"ms": ms[k], "model_tflops": t, "frac": t / PEAK_FP32_TFLOPS}
+    return out
+
+
 def stats_dict(s):
     return {"rng_draws": int(s.rng_draws), "shadow_samples": int(s.shadow_samples),
             "shade_points": int(s.shade_points), "gi_children": int(s.gi_children),
@@ -360,6 +382,10 @@ def main():
                          "kernel": ("wavefront pipeline (" + "+".join(ktimes) + ")") if ktimes else "crt::render_kernel",
                          "kernel_ms": kernel_ms, "render_call_ms": render_ms,
                          "kernels": {k: {"ms": ms, "launches": n} for k, (ms, n) in ktimes.items()},
+                         "per_kernel": per_kernel_roofline(ktimes, per_launch),
+                         "per_kernel_note": "model FLOPs by the kernel that does them: trace 450*shade_points + 40*gi_children, "
+                                            "filter+resolve 300*shadow_samples (97.8 % of the rays are decided by conservative "
+                                            "tests that cost a fraction of the exact test they stand for), shade 750*shade_points",
                          "peak_note": "157.3 = 256 CU x 4 SIMD x 16 lanes/clk x 2 (packed v_pk_fma_f32) x 2 flop x 2.4 GHz; "
                                       "a plain wave64 VALU instruction issues every 4 cycles per SIMD (78.6 TFLOP/s for unpacked fma)",
                          "flops_model": "300*shadow_samples + 1200*shade_points + 40*gi_children (rank 0's launch)"},
@@ -376,16 +402,34 @@ def main():
                 ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
                 ctx.render(st2, fb.data_ptr(), stream.cuda_stream)  # untimed warm-up
                 torch.cuda.synchronize(dev)
+                frames = 3 if other == "gl2" else 10
                 ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
                 torch.cuda.synchronize(dev)
                 t1 = time.perf_counter()
-                ctx.render(st2, fb.data_ptr(), stream.cuda_stream)
+                for _ in range(frames):
+                    ctx.render(st2, fb.data_ptr(), stream.cuda_stream)
                 torch.cuda.synchronize(dev)
-                dt = time.perf_counter() - t1
-                w2 = stats_dict(ctx.stats(st2))
-                rows[other] = {"ms": dt * 1e3, "Msamples_per_s": w2["shadow_samples"] / dt / 1e6,
+                dt = (time.perf_counter() - t1) / frames
+                w2 = {k: v / frames for k, v in stats_dict(ctx.stats(st2)).items()}
+                rows[other] = {"ms": dt * 1e3, "frames": frames, "Msamples_per_s": w2["shadow_samples"] / dt / 1e6,
                                "tflops_algorithmic": algorithmic_flops(w2) / dt / 1e12,
                                "speedup_vs_readme_rtx4070tis": README_4070TIS_S[other] / dt}
+                if other == "gl2":
+                    # the north-star workload with a roofline block of its own: the same frames again with the kernels'
+                    # HIP events on (which makes every frame wait for its last round, as a gl_iter 2 frame does anyway)
+                    ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
+                    ctx.set_timing(True)
+                    for _ in range(frames):
+                        ctx.render(st2, fb.data_ptr(), stream.cuda_stream)
+                    torch.cuda.synchronize(dev)
+                    kt = {k: (ms / frames, n / frames) for k, (ms, n) in ctx.kernel_times().items() if n}
+                    ctx.set_timing(False)
+                    kms = sum(ms for ms, _ in kt.values())
+                    ach = algorithmic_flops(w2) / (kms * 1e-3) / 1e12
+                    rows[other]["roofline"] = {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": ach / PEAK_FP32_TFLOPS, "kernel_ms": kms, "rounds": kt["trace"][1],
+                                               "kernels": {k: {"ms": ms, "launches": n} for k, (ms, n) in kt.items()},
+                                               "per_kernel": per_kernel_roofline(kt, w2), "work_per_frame": w2}
             out["readme_rows"] = rows
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(gl, 20.0)

@@ -49,7 +49,7 @@ struct crt_ctx {
     int audit = 0;
     int trace_mode = CRT_TRACE_AUTO;
     int coop_permille = -1; // CRT_COOP_PERMILLE as read by crt_create (tools/mix_sweep.sh); -1: by launch size
-    size_t workspace_limit = (size_t)32 << 30;
+    size_t workspace_limit = (size_t)96 << 30;
     crt::WfWorkspace wf;
 };
 
@@ -134,6 +134,18 @@ uint32_t pick_cooperative(const crt_ctx* ctx, const crt::RenderArgs& a) {
     return pixels < 200000ull ? 1000u : pixels < 400000ull ? 60u : 0u;
 }
 
+// wavefront_reserve within the context's workspace limit; when the device has less memory left than that, with
+// half the limit, a quarter, ... (a smaller workspace means more rounds, never another image).
+hipError_t reserve_workspace(crt_ctx* ctx, const crt::RenderArgs& a) {
+    hipError_t e = hipSuccess;
+    for (size_t budget = ctx->workspace_limit;; budget /= 2) {
+        e = crt::wavefront_reserve(ctx->wf, a, ctx->scene_host.n_lights, budget);
+        if (e != hipErrorOutOfMemory || budget < ((size_t)1 << 30)) break;
+        (void)hipGetLastError();
+    }
+    return e;
+}
+
 // Runs one launch through the pipeline the context selects.
 int run_render(crt_ctx* ctx, const crt::RenderArgs& args, hipStream_t stream) {
     crt::RenderArgs a = args;
@@ -145,7 +157,7 @@ int run_render(crt_ctx* ctx, const crt::RenderArgs& args, hipStream_t stream) {
         HIP_TRY(ctx, crt::launch_render(a, stream));
         return CRT_OK;
     }
-    const hipError_t reserved = crt::wavefront_reserve(ctx->wf, a, ctx->scene_host.n_lights, ctx->workspace_limit);
+    const hipError_t reserved = reserve_workspace(ctx, a);
     if (reserved != hipSuccess) {
         // no workspace (device memory exhausted): the persistent kernel needs none, so the default pipeline
         // still renders; only an explicit request for the wavefront kernels reports the failure
@@ -512,7 +524,7 @@ int crt_reserve_workspace(crt_ctx* ctx, const crt_settings* st, uint32_t rank, u
     a.n_units = world == 1 ? a.tiles_x * a.tiles_y : crt_shard_tiles(st->nx, st->ny, rank, world);
     a.cooperative = pick_cooperative(ctx, a); // before the check: the cooperative kernel needs more record slack
     if (!crt::wavefront_supports(a)) return CRT_OK; // crt_render takes the persistent kernel (or refuses, if told to use the pipeline)
-    const hipError_t reserved = crt::wavefront_reserve(ctx->wf, a, ctx->scene_host.n_lights, ctx->workspace_limit);
+    const hipError_t reserved = reserve_workspace(ctx, a);
     if (reserved != hipSuccess) {
         (void)hipGetLastError();
         // as in crt_render: without a workspace the default configuration renders with the persistent kernel

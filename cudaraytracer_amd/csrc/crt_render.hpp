@@ -74,6 +74,8 @@ struct WfWorkspace {
     // cooperative trace only
     float* draws = nullptr;         // [2 * CRT_RAY_STACK][n_lp]: the (r1, r2) pairs of the innermost node's children
     uint32_t* coop_tabs = nullptr;  // 63 jump tables: 1..63 shaded points' worth of draws
+    uint32_t* draw_tabs = nullptr;  // per-pixel trace: draw_tabs_n jump tables, table a-1 = the 2a draws of a child rays (a jump by any
+    uint32_t draw_tabs_n = 0;       // number of steps is the same map whatever it jumps over, so they do not depend on the settings)
     uint32_t coop_n = 0xffffffffu;  // draws per shaded point the tables were built for
     void* side_stream = nullptr;    // hipStream_t: the cooperative kernel of a mixed launch runs here
     void* fork_event = nullptr;     // hipEvent_t pair ordering the side stream against the caller's

@@ -107,6 +107,8 @@ struct WfArgs {
     float* draws;              // cooperative trace: [2 * CRT_RAY_STACK][n_lp] child draws of the innermost leaf node
     uint32_t work_static;      // record indices [0, work_static): the first chunk of every per-pixel trace wave, by its place
                                // in the launch; WF_CTR_WORK counts the chunks handed out behind them
+    const uint32_t* draw_tabs; // per-pixel trace: draw_tabs_n rng_jump tables in device memory, table a-1 jumps the 2a draws of a child rays
+    uint32_t draw_tabs_n;
     const uint32_t* coop_tabs; // cooperative trace: kCoopTables rng_jump tables in device memory, table k-1 jumps k shaded points' worth of draws
 };
 
@@ -192,7 +194,7 @@ struct Stage {
 constexpr uint32_t kNoRay = 0xffffffffu; // queue key of an entry that holds no ray
 // A queued ray's key: its shade record's index in the low kRecBits bits, its light above them.
 #ifndef CRT_REC_BITS
-#define CRT_REC_BITS 28
+#define CRT_REC_BITS 29
 #endif
 constexpr uint32_t kRecBits = CRT_REC_BITS, kRecMask = (1u << kRecBits) - 1u;
 constexpr uint64_t kRecLimit = 1ull << kRecBits;
@@ -907,6 +909,37 @@ constexpr uint32_t kCoopOwners = 64u / kCoopSplit;
 enum : uint32_t { OW_PRE = 0, OW_N, OW_LP, OW_NFRAMES, OW_CNT, OW_REM, OW_RNG, OW_RAY_D = OW_RNG + 6, OW_LANE = OW_RAY_D + 3, OW_SLOTS, OW_RECS, OW_WORDS };
 DI uint64_t lanes_below(uint32_t k) { return k >= 64u ? ~0ull : (1ull << k) - 1ull; }
 
+// XOR over the 64 lanes of a wave, returned to every lane (wave-uniform): within each row of 16 lanes by DPP
+// shifts (a lane without a source reads 0), then the rows' last lanes.
+DI uint32_t wave_xor(uint32_t x) {
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); // row_shr:1
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true); // row_shr:2
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); // row_shr:4
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true); // row_shr:8
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 15) ^ (uint32_t)__builtin_amdgcn_readlane((int)x, 31) ^
+           (uint32_t)__builtin_amdgcn_readlane((int)x, 47) ^ (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+// rng_jump of ONE generator state by the whole wave: the state's five words are wave-uniform, lane j < 40 looks up
+// the image of nibble j, the images are XORed across the lanes.  A lane that walks its pixel needs such a jump only
+// when it opens a frame (one lane in a hundred per step at gl_iter 1, one per step and wave at gl_iter 2); done by
+// that lane alone it costs the wave 40 look-ups of its own, done by the wave one.  The Weyl word is the caller's.
+DI void wave_jump(uint32_t (&v)[5], const uint32_t* tab, uint32_t lane) {
+    const uint32_t wd = lane >> 3;
+    const uint32_t word = wd == 0u ? v[0] : (wd == 1u ? v[1] : (wd == 2u ? v[2] : (wd == 3u ? v[3] : v[4])));
+    const uint32_t idx = (lane < 40u ? lane : 0u) * 16u + ((word >> (4u * (lane & 7u))) & 15u);
+    uint4 q = reinterpret_cast<const uint4*>(tab)[idx];
+    uint32_t q4 = tab[4u * kJumpEntries + idx];
+    if (lane >= 40u) {
+        q = make_uint4(0u, 0u, 0u, 0u);
+        q4 = 0u;
+    }
+    v[0] = wave_xor(q.x);
+    v[1] = wave_xor(q.y);
+    v[2] = wave_xor(q.z);
+    v[3] = wave_xor(q.w);
+    v[4] = wave_xor(q4);
+}
+
 // Children of the innermost frame leave last-to-first (main.cu:176-191 pushes, :132 pops):
 // get_random_ray_values_in_hemisphere (main.cu:60-74) and the child's attenuation (main.cu:186).
 DI void child_ray(V3 hp, V3 hn, V4 patt, V4 pdiff, float r1, float r2, float inv_ind, V3& o, V3& d, V4& att) {
@@ -1215,14 +1248,15 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                                                                                    uint32_t slot_end) {
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
-    __shared__ __attribute__((aligned(16))) uint32_t s_jump[2][kJumpWords];
+    // [0]: the draws of one shaded point; [1] (cooperative kernel only): the 2 ind_rays draws of an expanding hit's children
+    __shared__ __attribute__((aligned(16))) uint32_t s_jump[COOP ? 2 : 1][kJumpWords];
     // one row per primitive of the scene (dynamic, sized by the launch): with the two jump tables the workgroup
     // stays under 32 KB for scenes of up to 49 primitives, so that five workgroups fit a CU's LDS
     __shared__ uint32_t s_coop[COOP ? kTraceWaves : 1u][COOP ? kCoopOwners * OW_WORDS : 1u];
     __shared__ uint32_t s_coop_acc[COOP ? kTraceWaves : 1u][COOP ? kCoopOwners * 5u : 1u];
     extern __shared__ __attribute__((aligned(16))) float s_prim_words[];
     PrimRow* s_prim = reinterpret_cast<PrimRow*>(s_prim_words);
-    for (uint32_t k = threadIdx.x; k < 2u * kJumpWords; k += 64u * kTraceWaves)
+    for (uint32_t k = threadIdx.x; k < (COOP ? 2u : 1u) * kJumpWords; k += 64u * kTraceWaves)
         s_jump[k / kJumpWords][k % kJumpWords] = w.jump_tabs[k];
     fill_prim_table(sc, s_prim, threadIdx.x, 64u * kTraceWaves);
     __syncthreads();
@@ -1520,17 +1554,17 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                 if (skip_draws != 0u && skip_draws == w.jump_n[0]) rng_jump(rng, s_jump[0], skip_draws * 362437u);
                 else for (uint32_t k = 0; k < skip_draws; ++k) rng_step(rng);
 #endif
-                if (n_depth > 0u) {
+                if (COOP && n_depth > 0u) {
                     PROF_LANES(13);
                     ++cnt_expand;
                     // The reference draws (r1,r2) for every child and pushes while its stack has room (main.cu:176-191).
                     uint32_t room = on_stack < CRT_RAY_STACK ? CRT_RAY_STACK - on_stack : 0u;
                     uint32_t accepted = a.ind_rays < room ? a.ind_rays : room;
-                    if (COOP && n_depth == 1u) {
+                    if (n_depth == 1u) {
                         // leaf children: keep their draws where any lane of the wave can pick them up
                         for (uint32_t k = 0; k < 2u * accepted; ++k) w.draws[(size_t)k * n_lp + lp] = rng_uniform(rng);
                     } else if (accepted != 0u && 2u * accepted == w.jump_n[1]) {
-                        rng_jump(rng, s_jump[1], 2u * accepted * 362437u);
+                        rng_jump(rng, s_jump[COOP ? 1 : 0], 2u * accepted * 362437u);
                     } else {
                         for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
                     }
@@ -1545,6 +1579,50 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                         on_stack += accepted;
                     }
                     for (uint32_t k = 2u * accepted; k < 2u * a.ind_rays; ++k) rng_step(rng);
+                }
+            }
+            if (!COOP) {
+                // ---- expanding hits: the reference draws (r1,r2) for every one of the ind_rays children and pushes
+                // while its stack has room (main.cu:176-191).  The frame keeps the generator state behind the draws of
+                // the `accepted` children it holds (they are stepped back out of it one by one), the pixel goes on
+                // behind all 2 ind_rays draws.  Both are jumps of one lane's state, made by the whole wave.
+                const bool push = emit && n_depth > 0u;
+                uint32_t accepted = 0;
+                if (push) {
+                    PROF_LANES(13);
+                    ++cnt_expand;
+                    const uint32_t room = on_stack < CRT_RAY_STACK ? CRT_RAY_STACK - on_stack : 0u;
+                    accepted = a.ind_rays < room ? a.ind_rays : room;
+                }
+                Rng fgen = rng; // generator state the frame keeps
+                for (uint64_t pmask = __ballot(push); pmask != 0ull; pmask &= pmask - 1ull) {
+                    const int src = __builtin_ctzll(pmask);
+                    uint32_t v[5] = {(uint32_t)__builtin_amdgcn_readlane((int)rng.v0, src), (uint32_t)__builtin_amdgcn_readlane((int)rng.v1, src),
+                                     (uint32_t)__builtin_amdgcn_readlane((int)rng.v2, src), (uint32_t)__builtin_amdgcn_readlane((int)rng.v3, src),
+                                     (uint32_t)__builtin_amdgcn_readlane((int)rng.v4, src)};
+                    const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)accepted, src);
+                    for (uint32_t left = acc; left != 0u;) { // (more children than tables: ind_rays above CRT_RAY_STACK never are accepted)
+                        const uint32_t n = left < w.draw_tabs_n ? left : w.draw_tabs_n;
+                        wave_jump(v, w.draw_tabs + (size_t)(n - 1u) * kJumpWords, lane);
+                        left -= n;
+                    }
+                    if (lane == (uint32_t)src) fgen = Rng{v[0], v[1], v[2], v[3], v[4], rng.d + 2u * acc * 362437u};
+                    for (uint32_t left = a.ind_rays - acc; left != 0u;) {
+                        const uint32_t n = left < w.draw_tabs_n ? left : w.draw_tabs_n;
+                        wave_jump(v, w.draw_tabs + (size_t)(n - 1u) * kJumpWords, lane);
+                        left -= n;
+                    }
+                    if (lane == (uint32_t)src) rng = Rng{v[0], v[1], v[2], v[3], v[4], rng.d + 2u * a.ind_rays * 362437u};
+                }
+                if (push && accepted > 0u) {
+                    uint4* f = frame_at(w, nframes, lp);
+                    ++nframes;
+                    f[FG_POINT * n_lp] = make_uint4(f2u(n_P.x), f2u(n_P.y), f2u(n_P.z), n_geom);
+                    f[FG_NORMAL * n_lp] = make_uint4(f2u(n_N.x), f2u(n_N.y), f2u(n_N.z), n_depth - 1u);
+                    f[FG_ATT * n_lp] = make_uint4(f2u(n_att.x), f2u(n_att.y), f2u(n_att.z), f2u(n_att.w));
+                    f[FG_GEN * n_lp] = make_uint4(fgen.v0, fgen.v1, fgen.v2, fgen.v3);
+                    f[FG_GEN2 * n_lp] = make_uint4(fgen.v4, fgen.d, accepted, 0u);
+                    on_stack += accepted;
                 }
             }
         }
@@ -2014,7 +2092,7 @@ __global__ void __launch_bounds__(64, 4) wf_resolve_kernel(WfArgs w) {
     const uint32_t n_lights = sc->n_lights;
     // rays whose closest hit is glass wait here until 64 of them can walk together
     __shared__ float gq_f[9][kGlassCap];    // origin, direction, first hit (t, u, v)
-    __shared__ uint32_t gq_u[2][kGlassCap]; // queue key (record | light << 28), primitive
+    __shared__ uint32_t gq_u[2][kGlassCap]; // queue key (record | light << kRecBits), primitive
     uint32_t gq = 0;                        // wave-uniform fill
     // the queue's fill is whatever the filter kernel left in the device counter
     const uint32_t qcount = min(w.ctrs[WF_CTR_QUEUE], w.qcap);
@@ -2351,9 +2429,9 @@ constexpr uint32_t kMinQuota = 8;
 
 } // namespace
 
-// A shade record's index shares a 32-bit word with its light (28 + 4 bits), and every pixel slot needs at
+// A shade record's index shares a 32-bit word with its light (29 + 3 bits), and every pixel slot needs at
 // least 8 result slots plus its share of partly used record chunks per round: launches of more than about
-// 15 million pixel slots (for example 4096 x 4096) do not fit.
+// 31 million pixel slots (for example 5800 x 5800) do not fit.
 bool wavefront_supports(const RenderArgs& a) {
     const uint64_t n_lp = (uint64_t)a.n_units * 64u;
     if (n_lp == 0) return true;
@@ -2386,6 +2464,7 @@ void wavefront_release(WfWorkspace& ws) {
     (void)hipFree(ws.queue);
     (void)hipFree(ws.jump_dev);
     (void)hipFree(ws.coop_tabs);
+    (void)hipFree(ws.draw_tabs);
     (void)hipFree(ws.backup);
     delete static_cast<EventTimer*>(ws.timer);
     (void)hipFree(ws.draws);
@@ -2740,6 +2819,8 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     w.jump_n[1] = ws.jump_n[1];
     w.draws = ws.draws;
     w.coop_tabs = ws.coop_tabs;
+    w.draw_tabs = ws.draw_tabs;
+    w.draw_tabs_n = ws.draw_tabs_n;
     w.work_static = 0u;
     w.unit_order = nullptr;
     ws.single_round = args.aa_iter <= 1u && slots_per_pixel(args) <= ws.quota;
@@ -2798,6 +2879,28 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         }
         w.jump_n[0] = ws.jump_n[0];
         w.jump_n[1] = ws.jump_n[1];
+        // per-pixel trace kernel: one table per number of children an expanding hit can keep, 2a draws each
+        const uint32_t n_child_tabs = args.gl_iter == 0u ? 0u : (args.ind_rays < CRT_RAY_STACK ? args.ind_rays : CRT_RAY_STACK);
+        if (n_child_tabs != 0u && n_coop != args.n_units && (ws.draw_tabs_n != n_child_tabs || !ws.draw_tabs)) {
+            if (ws.draw_tabs) {
+                e = hipStreamSynchronize(stream);
+                if (e != hipSuccess) return e;
+                (void)hipFree(ws.draw_tabs);
+                ws.draw_tabs = nullptr;
+                ws.draw_tabs_n = 0;
+            }
+            std::vector<uint32_t> tabs((size_t)n_child_tabs * kJumpWords, 0u);
+            build_jump_table(2u, tabs.data());
+            for (uint32_t t = 1; t < n_child_tabs; ++t)
+                compose_jump_tables(tabs.data() + (size_t)(t - 1u) * kJumpWords, tabs.data(), tabs.data() + (size_t)t * kJumpWords);
+            e = hipMalloc((void**)&ws.draw_tabs, tabs.size() * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemcpyAsync(ws.draw_tabs, tabs.data(), tabs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return e;
+            ws.draw_tabs_n = n_child_tabs;
+        }
+        w.draw_tabs = ws.draw_tabs;
+        w.draw_tabs_n = ws.draw_tabs_n;
         if (coop && ws.coop_n != want[0]) {
             std::vector<uint32_t> tabs((size_t)kCoopTables * kJumpWords, 0u);
             // table k-1 = k times the jump of one shaded point

@@ -234,7 +234,7 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out);
 
 /* Which kernels crt_render / crt_render_partial / crt_render_shard run.  Both give the same bits.
  *   CRT_PIPELINE_AUTO        the wavefront pipeline (default); the persistent kernel for launches the
- *                            pipeline cannot hold (more than about 15 million pixels at once, e.g. 4096 x 4096,
+ *                            pipeline cannot hold (more than about 31 million pixels at once, e.g. 5800 x 5800,
  *                            or no device memory left for its workspace)
  *   CRT_PIPELINE_PERSISTENT  one persistent kernel per launch, asynchronous on `stream`, no workspace
  *   CRT_PIPELINE_WAVEFRONT   trace / filter / resolve / shade / sum kernels with records in device
@@ -285,7 +285,8 @@ int crt_audit_result(crt_ctx* ctx, uint64_t* checked, uint64_t* contradictions);
  * crt_render_shard(rank, world) with these settings now, instead of inside the first render call.
  * Optional; a no-op for the persistent pipeline.  Synchronous. */
 int crt_reserve_workspace(crt_ctx* ctx, const crt_settings* st, uint32_t rank, uint32_t world);
-/* Upper bound in bytes of the wavefront pipeline's device workspace (default 32 GiB); a smaller
+/* Upper bound in bytes of the wavefront pipeline's device workspace (default 96 GiB, of which a launch takes
+ * what its rounds can use; if the device has less left, the library halves the bound until it fits); a smaller
  * bound means more rounds per image, never a different image.  No counterpart in the reference. */
 int crt_set_workspace_limit(crt_ctx* ctx, size_t bytes);
 /* Measuring aid: wavefront frames of this context stop after `rounds` pipeline rounds (0, the default: no

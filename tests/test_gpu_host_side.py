@@ -91,9 +91,10 @@ def test_a_rejected_scene_upload_leaves_the_previous_scene_in_place(oracle):
 
 
 def test_a_launch_too_large_for_the_pipeline_takes_the_persistent_kernel():
-    """4100 x 4100 pixels exceed the wavefront pipeline's record index; the default configuration renders them
-    with the persistent kernel instead of failing, an explicit request for the pipeline is refused."""
-    st = crt.make_settings(nx=4100, ny=4100, aa_iter=0, gl_iter=0, shadowSamples=1)
+    """5800 x 5800 pixels exceed the wavefront pipeline's record index (29 bits next to the light's 3); the default
+    configuration renders them with the persistent kernel instead of failing, an explicit request for the
+    pipeline is refused."""
+    st = crt.make_settings(nx=5800, ny=5800, aa_iter=0, gl_iter=0, shadowSamples=1)
     with crt.Context(0) as ctx:
         ctx.upload(crt.cornell_box(1))
         ctx.rng_init(st.nx, st.ny, 2)
@@ -102,7 +103,7 @@ def test_a_launch_too_large_for_the_pipeline_takes_the_persistent_kernel():
         try:
             ctx.render(st, fb)
             img = ctx.fb_download(fb, n).reshape(st.ny, st.nx, 4)
-            assert img[..., 3].min() >= 0.0 and img[2050, 2050, 0] > 0.0
+            assert img[..., 3].min() >= 0.0 and img[2900, 2900, 0] > 0.0
             ctx.set_pipeline(abi.CRT_PIPELINE_WAVEFRONT)
             with pytest.raises(crt.CrtError) as err:
                 ctx.render(st, fb)
