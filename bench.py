@@ -250,6 +250,10 @@ def main():
                     help="kernels behind crt_render: auto = wavefront pipeline where it applies")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-rows", action="store_true", help="skip the extra gl0/gl2 README rows at N=1")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of N > 1 on a one-GPU box: every rank renders its shard on GPU 0 and the gather goes "
+                         "over gloo through host memory (RCCL does not put two ranks on one device); not a scaling measurement")
+    ap.add_argument("--frame-sha", action="store_true", help="add the SHA-256 of the last assembled frame to the line")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher, process group (gloo) and gather/scatter only, on CPU tensors: no GPU, no render")
     args = ap.parse_args()
@@ -273,18 +277,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = torch.device("cpu") if args.share_gpu else dev  # where the scalar reductions below live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.workload == "c5":
         return config5(args, torch, crt)
     gl = int(args.workload[2])
     nx, ny = args.nx, args.ny
     st = crt.make_settings(nx=nx, ny=ny, gl_iter=gl)
-    ctx = crt.Context(local_rank)
+    ctx = crt.Context(dev_index)
     ctx.set_pipeline({"auto": crt.abi.CRT_PIPELINE_AUTO, "wavefront": crt.abi.CRT_PIPELINE_WAVEFRONT,
                       "persistent": crt.abi.CRT_PIPELINE_PERSISTENT}[args.pipeline])
     ctx.upload(crt.cornell_box(st.shadowSamples))
@@ -337,11 +346,11 @@ def main():
     kernel_ms = sum(ms for ms, _ in ktimes.values()) if ktimes else render_ms
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         w = torch.tensor([work["shadow_samples"], work["shade_points"], work["gi_children"], work["rng_draws"]],
-                         dtype=torch.int64, device=dev)
+                         dtype=torch.int64, device=red_dev)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
         total = dict(zip(["shadow_samples", "shade_points", "gi_children", "rng_draws"], [int(x) for x in w.tolist()]))
     else:
@@ -391,6 +400,11 @@ def main():
                          "flops_model": "300*shadow_samples + 1200*shade_points + 40*gi_children (rank 0's launch)"},
             "work_per_step": {k: v / args.steps for k, v in total.items()},
         }
+        if args.share_gpu:
+            out["rehearsal"] = "all ranks on GPU 0, gather over gloo through host memory: plumbing only, not a scaling number"
+        if args.frame_sha:
+            import hashlib
+            out["frame_sha256"] = hashlib.sha256(fb.cpu().numpy().tobytes()).hexdigest()
         if nx == 720 and ny == 720:
             out["speedup_vs_readme_rtx4070tis"] = README_4070TIS_S[args.workload] / (ms_per_step * 1e-3)
         if world == 1 and not args.no_rows and nx == 720 and ny == 720:

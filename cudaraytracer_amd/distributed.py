@@ -68,12 +68,17 @@ def gather_image(compact, nx, ny, ctx=None, fb=None):
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     if world > 1:
-        gathered = torch.empty((world, compact.numel()), dtype=compact.dtype, device=compact.device) \
-            if rank == 0 else None
+        # RCCL gathers device buffers directly; under gloo (several ranks rehearsing on one GPU, or CPU tensors)
+        # the shard goes through host memory
+        staged = compact.is_cuda and dist.get_backend() == "gloo"
+        send = compact.cpu() if staged else compact
+        gathered = torch.empty((world, send.numel()), dtype=send.dtype, device=send.device) if rank == 0 else None
         parts = [gathered[r] for r in range(world)] if rank == 0 else None
-        dist.gather(compact, gather_list=parts, dst=0)
+        dist.gather(send, gather_list=parts, dst=0)
         if rank != 0:
             return None
+        if staged:
+            gathered = gathered.to(compact.device)
     else:
         gathered = compact.unsqueeze(0)
     if compact.is_cuda:

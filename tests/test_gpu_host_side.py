@@ -110,3 +110,29 @@ def test_a_launch_too_large_for_the_pipeline_takes_the_persistent_kernel():
             assert err.value.code == abi.CRT_ERR_UNSUPPORTED
         finally:
             ctx.fb_free(fb)
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_on_one_gpu_assembles_the_single_rank_frame():
+    """`python bench.py --gpus 2` starts its own two ranks; with --share-gpu both render their interleaved tiles on
+    GPU 0 and rank 0 gathers them (over gloo, RCCL needs a GPU per rank) and scatters them: everything of the
+    N > 1 path but the RCCL call itself.  The assembled frame must be the one-rank frame bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu", "--no-rows", "--frame-sha", "--nx", "96", "--ny", "64", "--workload", "gl1"]
+    lines = []
+    for flags in (["--gpus", "1"], ["--gpus", "2", "--share-gpu"]):
+        p = subprocess.run([sys.executable, str(root / "bench.py"), *flags, *common], capture_output=True, text=True, timeout=280, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(out) == 1, p.stdout
+        lines.append(json.loads(out[0]))
+    one, two = lines
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["steps"] == 2
+    assert two["frame_sha256"] == one["frame_sha256"]
+    assert two["work_per_step"]["shadow_samples"] == one["work_per_step"]["shadow_samples"]
