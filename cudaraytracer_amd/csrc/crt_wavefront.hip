@@ -46,7 +46,7 @@ namespace crt {
 namespace {
 
 // slot tags: type in bits 0..1; an end-of-call tag carries its AA task's level (bits 2..4) and corner (bits 5..6)
-enum : uint32_t { TAG_ADD = 0, TAG_END_CALL = 1, TAG_END_PIXEL = 2 };
+enum : uint32_t { TAG_ADD = 0, TAG_END_CALL = 1, TAG_END_PIXEL = 2, TAG_SKIP = 3 /* a slot without a result */ };
 // verdict of the sum kernel on a finished level >= 2 AA task (main.cu:283-300)
 enum : uint32_t { AA_PENDING = 0, AA_ALL_EQUAL = 1, AA_SUBDIVIDE = 2 };
 constexpr uint32_t kWorkChunk = 256;         // shade-record indices a trace wave reserves at a time
@@ -905,6 +905,19 @@ DI void ordinal_jump(Rng& rng, uint32_t k, const WfArgs& w) { // k shaded points
 // of them in flight.
 constexpr uint32_t kCoopSplit = 8;
 constexpr uint32_t kCoopOwners = 64u / kCoopSplit;
+constexpr uint32_t kCoopList = 512; // >= kCoopOwners * kCoopBatch: children one step of a wave can have in its list
+static_assert(kCoopOwners * kCoopBatch <= kCoopList, "list positions");
+// bits [lo, hi) set in a bit array
+DI uint32_t count_bits(const uint32_t* bits, uint32_t lo, uint32_t hi) {
+    uint32_t n = 0;
+    for (uint32_t wd = lo >> 5; wd <= (hi >> 5) && wd < kCoopList / 32u; ++wd) {
+        uint32_t m = bits[wd];
+        if (wd == (lo >> 5)) m &= ~0u << (lo & 31u);
+        if (wd == (hi >> 5)) m &= (hi & 31u) ? ~(~0u << (hi & 31u)) : 0u;
+        n += (uint32_t)__popc(m);
+    }
+    return n;
+}
 // what the cooperative expansion keeps per owner in LDS while the wave works through the owners' children
 enum : uint32_t { OW_PRE = 0, OW_N, OW_LP, OW_NFRAMES, OW_CNT, OW_REM, OW_RNG, OW_RAY_D = OW_RNG + 6, OW_LANE = OW_RAY_D + 3, OW_SLOTS, OW_RECS, OW_WORDS };
 DI uint64_t lanes_below(uint32_t k) { return k >= 64u ? ~0ull : (1ull << k) - 1ull; }
@@ -1109,6 +1122,27 @@ DI void store_record(const WfArgs& w, uint32_t wi, V3 P, V3 N, V3 view, V4 att, 
     }
 }
 
+// The same without the word that says what the record is (primitive | ordinal): the cooperative kernel writes that
+// word at the end of its step (disjoint bytes: the two stores cannot overtake each other's data).
+DI void store_record_body(const WfArgs& w, uint32_t wi, V3 P, V3 N, V3 view, V4 att, const Rng& rng, uint32_t slot) {
+    if (wi < w.cap_work) {
+        uint32_t* pt = reinterpret_cast<uint32_t*>(rec_point(w) + wi);
+        __builtin_nontemporal_store(f2u(P.x), pt + 0);
+        __builtin_nontemporal_store(f2u(P.y), pt + 1);
+        __builtin_nontemporal_store(f2u(P.z), pt + 2);
+        const size_t cw_ = w.cap_work;
+        uint4* sf = rec_surface(w) + wi;
+        store_streaming(sf, make_uint4(f2u(N.x), f2u(N.y), f2u(N.z), slot));
+        store_streaming(sf + cw_, make_uint4(f2u(view.x), f2u(view.y), f2u(view.z), f2u(att.w)));
+        store_streaming(sf + 2 * cw_, make_uint4(f2u(att.x), f2u(att.y), f2u(att.z), 0u));
+        uint4* gn = rec_gen(w) + wi;
+        store_streaming(gn, make_uint4(rng.v0, rng.v1, rng.v2, rng.v3));
+        store_streaming(gn + cw_, make_uint4(rng.v4, rng.d, 0u, 0u));
+    } else {
+        w.ctrs[WF_CTR_ERROR] = 1u;
+    }
+}
+
 // The wave's cursor into the shade-record array: records are handed out in chunks of kWorkChunk
 // consecutive indices, so the one global counter sees one atomic per chunk instead of one per step.
 struct WorkCursor {
@@ -1254,6 +1288,9 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
     // stays under 32 KB for scenes of up to 49 primitives, so that five workgroups fit a CU's LDS
     __shared__ uint32_t s_coop[COOP ? kTraceWaves : 1u][COOP ? kCoopOwners * OW_WORDS : 1u];
     __shared__ uint32_t s_coop_acc[COOP ? kTraceWaves : 1u][COOP ? kCoopOwners * 5u : 1u];
+    __shared__ uint32_t s_pend[COOP ? kTraceWaves : 1u][COOP ? kCoopList : 1u];
+    __shared__ uint8_t s_pgeom[COOP ? kTraceWaves : 1u][COOP ? kCoopList : 4u];
+    __shared__ uint32_t s_hitbits[COOP ? kTraceWaves : 1u][COOP ? kCoopList / 32u : 1u];
     extern __shared__ __attribute__((aligned(16))) float s_prim_words[];
     PrimRow* s_prim = reinterpret_cast<PrimRow*>(s_prim_words);
     for (uint32_t k = threadIdx.x; k < (COOP ? 2u : 1u) * kJumpWords; k += 64u * kTraceWaves)
@@ -1629,10 +1666,9 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
         PROF_MARK(2);
         if (COOP) {
             // ---- leaf children: one lane per child ray.  The owners (pixels) that want their innermost frame expanded
-            // put up to kCoopBatch children each into one list, in lane order, and the wave works through the list 64
-            // entries at a time, so a batch can hold the children of two or more owners (75 children per owner are
-            // 10 batches for the wave's 8 owners instead of 16).  Every child fills at most one result slot, so
-            // n <= quota - cnt children of an owner respect its quota.
+            // put up to kCoopBatch children each into one list, in lane order, and the wave's lanes work through the
+            // list (below).  Every child takes one result slot, so n <= quota - cnt children of an owner respect its
+            // quota.
             const uint64_t cm = __ballot(want_coop);
             if (cm != 0) {
                 uint32_t* own_tab = s_coop[threadIdx.x >> 6]; // [kCoopOwners][OW_WORDS], this wave's
@@ -1667,99 +1703,128 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                     oj[OW_RAY_D + 1] = f2u(ray_d.y);
                     oj[OW_RAY_D + 2] = f2u(ray_d.z);
                     oj[OW_LANE] = lane;
-                    oj[OW_SLOTS] = 0u; // result slots / diffuse hits of this owner in earlier batches of the list
-                    oj[OW_RECS] = 0u;
+                    oj[OW_RECS] = 0u; // diffuse hits among its children of this step (filled in at the end)
                 }
-                for (uint32_t b0 = 0; b0 < total; b0 += 64u) {
-                    const uint32_t p = b0 + lane;
-                    const bool act = p < total;
-                    uint32_t j = 0; // the owner whose children cover list position p
-                    for (uint32_t jj = 1; jj < n_own; ++jj)
-                        if (p >= own_tab[jj * OW_WORDS + OW_PRE]) j = jj;
-                    const uint32_t* oj = own_tab + j * OW_WORDS;
-                    const uint32_t o_lp = oj[OW_LP], o_rem = oj[OW_REM];
-                    V3 c_ray_d = mk3(u2f(oj[OW_RAY_D + 0]), u2f(oj[OW_RAY_D + 1]), u2f(oj[OW_RAY_D + 2]));
-                    const uint4* f = frame_at(w, oj[OW_NFRAMES] - 1u, o_lp);
-                    const uint4 fp = f[FG_POINT * n_lp], fn = f[FG_NORMAL * n_lp], fa = f[FG_ATT * n_lp];
-                    const V3 hp = mk3(u2f(fp.x), u2f(fp.y), u2f(fp.z));
-                    const V3 hn = mk3(u2f(fn.x), u2f(fn.y), u2f(fn.z));
-                    const V4 patt = V4{u2f(fa.x), u2f(fa.y), u2f(fa.z), u2f(fa.w)};
-                    const float* fpr = s_prim[fp.w];
-                    const V4 pdiff = V4{fpr[12], fpr[13], fpr[14], fpr[15]};
-                    // the c-th child of its owner to leave the stack: child rem-1-c, drawn as pair rem-1-c
-                    const uint32_t child = o_rem - 1u - (act ? p - oj[OW_PRE] : 0u);
-                    const float r1 = w.draws[(size_t)(2u * child) * n_lp + o_lp];
-                    const float r2 = w.draws[(size_t)(2u * child + 1u) * n_lp + o_lp];
-                    V3 c_o, c_d;
-                    V4 c_att;
-                    child_ray(hp, hn, patt, pdiff, r1, r2, inv_ind, c_o, c_d, c_att);
-                    uint32_t c_ref = a.ref_iter;
+                // what the list's children leave behind for the end of the step: the record of a child that ended in a
+                // diffuse hit (its index and primitive; the record's ordinal is known only when every earlier child
+                // of its owner has ended), and which children ended in a diffuse hit at all
+                uint32_t* pend = s_pend[threadIdx.x >> 6];
+                uint8_t* pgeom = s_pgeom[threadIdx.x >> 6];
+                uint32_t* hitbits = s_hitbits[threadIdx.x >> 6];
+                for (uint32_t q = lane; q < total; q += 64u) pend[q] = kNoRecord;
+                if (lane < kCoopList / 32u) hitbits[lane] = 0u;
+                // ---- the wave's lanes take the list's children in order, one each; a lane keeps its child until the
+                // child's chain of mirror / glass bounces has ended (main.cu:132-221 with gl_depth 0) and then takes the
+                // next one, so every pass over the scene runs on 64 rays while children are left -- working through the
+                // list 64 at a time, each batch until its longest chain has ended, took 2.2 passes per batch.
+                uint32_t next = 0;     // list position of the next child to hand out (wave-uniform)
+                bool running = false;  // this lane holds a child whose chain has not ended
+                uint32_t c_pos = 0, c_j = 0, c_ref = 0, c_lp = 0;
+                V3 c_o = mk3(0, 0, 0), c_d = mk3(0, 0, 0), c_ray_d = mk3(0, 0, -1.0f);
+                V4 c_att = V4{0, 0, 0, 0};
+                for (;;) {
+                    const uint64_t fm = __ballot(!running);
+                    const uint32_t left = total - next;
+                    if (left == 0u && fm == ~0ull) break;
+                    const uint32_t fr = lane_rank(fm);
+                    if (!running && fr < left) {
+                        const uint32_t pp = next + fr;
+                        uint32_t j = 0; // the owner whose children cover list position pp
+                        for (uint32_t jj = 1; jj < n_own; ++jj)
+                            if (pp >= own_tab[jj * OW_WORDS + OW_PRE]) j = jj;
+                        const uint32_t* oj = own_tab + j * OW_WORDS;
+                        const uint32_t o_lp = oj[OW_LP], o_rem = oj[OW_REM];
+                        c_ray_d = mk3(u2f(oj[OW_RAY_D + 0]), u2f(oj[OW_RAY_D + 1]), u2f(oj[OW_RAY_D + 2]));
+                        const uint4* f = frame_at(w, oj[OW_NFRAMES] - 1u, o_lp);
+                        const uint4 fp = f[FG_POINT * n_lp], fn = f[FG_NORMAL * n_lp], fa = f[FG_ATT * n_lp];
+                        const V3 hp = mk3(u2f(fp.x), u2f(fp.y), u2f(fp.z));
+                        const V3 hn = mk3(u2f(fn.x), u2f(fn.y), u2f(fn.z));
+                        const V4 patt = V4{u2f(fa.x), u2f(fa.y), u2f(fa.z), u2f(fa.w)};
+                        const float* fpr = s_prim[fp.w];
+                        const V4 pdiff = V4{fpr[12], fpr[13], fpr[14], fpr[15]};
+                        // the c-th child of its owner to leave the stack: child rem-1-c, drawn as pair rem-1-c
+                        const uint32_t child = o_rem - 1u - (pp - oj[OW_PRE]);
+                        const float r1 = w.draws[(size_t)(2u * child) * n_lp + o_lp];
+                        const float r2 = w.draws[(size_t)(2u * child + 1u) * n_lp + o_lp];
+                        child_ray(hp, hn, patt, pdiff, r1, r2, inv_ind, c_o, c_d, c_att);
+                        c_ref = a.ref_iter;
+                        c_pos = pp;
+                        c_j = j;
+                        c_lp = o_lp;
+                        running = true;
+                    }
+                    next += (uint32_t)__popcll(fm) < left ? (uint32_t)__popcll(fm) : left;
                     PROF_MARK(4);
-                    // the child's chain of mirror / glass bounces (main.cu:132-221 with gl_depth 0)
-                    uint32_t outcome = 0; // 0 no slot (bounces used up), 1 miss, 2 diffuse hit
+                    // ---- one pop for every lane that holds a ray
+                    uint32_t outcome = 3u; // 0 ended without a result (bounces used up), 1 miss, 2 diffuse hit, 3 still running / idle
                     V3 c_P = mk3(0, 0, 0), c_N = mk3(0, 0, 0), c_view = mk3(0, 0, 0);
                     V4 r_att = V4{0, 0, 0, 0};
                     uint32_t c_geom = 0;
-                    bool running = act;
-                    while (__any(running)) {
-                        if (running) {
-                            running = false;
-                            if (c_ref != 0u) {
-                                c_view = neg(c_d);
-                                r_att = c_att;
-                                const uint32_t what = pop_ray(sc, s_prim, c_o, c_d, c_att, c_ref, c_ray_d, c_P, c_N, c_geom);
-                                if (what == POP_MISS) outcome = 1u;
-                                else if (what == POP_DIFFUSE) outcome = 2u;
-                                else running = true;
-                            }
+                    if (running) {
+                        if (c_ref == 0u) {
+                            outcome = 0u;
+                        } else {
+                            c_view = neg(c_d);
+                            r_att = c_att;
+                            const uint32_t what = pop_ray(sc, s_prim, c_o, c_d, c_att, c_ref, c_ray_d, c_P, c_N, c_geom);
+                            if (what == POP_MISS) outcome = 1u;
+                            else if (what == POP_DIFFUSE) outcome = 2u;
                         }
+                        if (outcome != 3u) running = false;
                     }
                     PROF_MARK(5);
-                    // m_rec: the batch's diffuse hits in list order; within an owner that is child order, and each
-                    // moves the owner's generator by one shaded point
-                    const uint64_t m_slot = __ballot(outcome != 0u), m_rec = __ballot(outcome == 2u);
-                    // the lanes of this batch that hold children of the same owner, and those of them below this lane
-                    // (the owner's entry is read again here rather than held in registers through the chains)
-                    const uint32_t o_pre = oj[OW_PRE], o_n = oj[OW_N], o_cnt = oj[OW_CNT];
-                    const uint32_t before_slots = oj[OW_SLOTS], before_recs = oj[OW_RECS];
-                    const uint32_t seg_lo = o_pre > b0 ? o_pre - b0 : 0u;
-                    const uint32_t seg_hi = o_pre + o_n - b0 < 64u ? o_pre + o_n - b0 : 64u;
-                    const uint64_t seg = lanes_below(seg_hi) & ~lanes_below(seg_lo);
-                    const uint64_t below = seg & lanes_below(lane);
-                    const uint32_t slot_k = o_cnt + before_slots + (uint32_t)__popcll(m_slot & below);
-                    const uint32_t ordinal = before_recs + (uint32_t)__popcll(m_rec & below);
+                    // ---- the children that ended in this pass.  A child's result slot is its place in the list (the
+                    // sum kernel adds a pixel's slots in order, which is the order the children leave the stack in; a
+                    // child that ended without a result marks its slot as one to skip).
+                    const uint32_t* oj = own_tab + c_j * OW_WORDS;
+                    const uint32_t o_pre = oj[OW_PRE], o_n = oj[OW_N];
+                    const size_t slot = slot_at(w, oj[OW_CNT] + (c_pos - o_pre), c_lp);
                     float4 dark_c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     const bool dark = outcome == 2u && ambient_only(sc, s_prim, c_P, c_geom, r_att, dark_c);
                     const uint64_t m_store = __ballot(outcome == 2u && !dark); // those that become records
+                    if (outcome == 0u) w.tags[slot] = (uint8_t)TAG_SKIP;
                     if (outcome == 1u) {
                         const V4 c = r_att * V4{0.0f, 0.0f, 0.0f, 1.0f};
-                        store_streaming(&w.contrib[slot_at(w, slot_k, o_lp)], make_float4(c.x, c.y, c.z, c.w));
+                        store_streaming(&w.contrib[slot], make_float4(c.x, c.y, c.z, c.w));
                     }
-                    if (dark) store_streaming(&w.contrib[slot_at(w, slot_k, o_lp)], dark_c);
+                    if (dark) store_streaming(&w.contrib[slot], dark_c);
+                    if (outcome == 2u) atomicOr(&hitbits[c_pos >> 5], 1u << (c_pos & 31u)); // dark or not: a shaded point
                     if (m_store != 0) {
-                        // the k-th diffuse hit of an owner keeps the owner's generator state and k
+                        // the record keeps the owner's generator state; its ordinal (how many shaded points further on
+                        // its own draws start) follows at the end of the step
                         const uint32_t my_wi = reserve_records(w, wc, m_store, lane);
                         if (outcome == 2u && !dark) {
                             const Rng o_rng = Rng{oj[OW_RNG + 0], oj[OW_RNG + 1], oj[OW_RNG + 2], oj[OW_RNG + 3], oj[OW_RNG + 4], oj[OW_RNG + 5]};
-                            store_record(w, my_wi, c_P, c_N, c_view, r_att, c_geom, o_rng, (uint32_t)slot_at(w, slot_k, o_lp), ordinal);
+                            store_record_body(w, my_wi, c_P, c_N, c_view, r_att, o_rng, (uint32_t)slot);
+                            pend[c_pos] = my_wi < w.cap_work ? my_wi : kNoRecord;
+                            pgeom[c_pos] = (uint8_t)c_geom;
                         }
+                    }
+                    // the owner's last child leaves the direction register (main.cu:138: the last ray that had a usable direction)
+                    if (outcome != 3u && c_pos + 1u == o_pre + o_n) {
+                        uint32_t* ow = own_tab + c_j * OW_WORDS;
+                        ow[OW_RAY_D + 0] = f2u(c_ray_d.x);
+                        ow[OW_RAY_D + 1] = f2u(c_ray_d.y);
+                        ow[OW_RAY_D + 2] = f2u(c_ray_d.z);
                     }
                     PROF_MARK(6);
-                    // ---- the last lane of an owner's run in this batch keeps the owner's counts up to date, and the
-                    // lane of its last child leaves the direction register (main.cu:138: the last ray that had a usable
-                    // direction)
-                    if (act && lane + 1u == seg_hi) {
-                        uint32_t* ow = own_tab + j * OW_WORDS;
-                        ow[OW_SLOTS] = before_slots + (uint32_t)__popcll(m_slot & seg);
-                        ow[OW_RECS] = before_recs + (uint32_t)__popcll(m_rec & seg);
-                        if (p + 1u == o_pre + o_n) {
-                            ow[OW_RAY_D + 0] = f2u(c_ray_d.x);
-                            ow[OW_RAY_D + 1] = f2u(c_ray_d.y);
-                            ow[OW_RAY_D + 2] = f2u(c_ray_d.z);
-                        }
-                    }
-                    PROF_MARK(7);
                 }
+                // ---- every child has ended: the records' ordinals (diffuse hits among the earlier children of the same
+                // owner) and, per owner, its number of diffuse hits
+                for (uint32_t q = lane; q < total; q += 64u) {
+                    const uint32_t wi = pend[q];
+                    if (wi == kNoRecord) continue;
+                    uint32_t j = 0;
+                    for (uint32_t jj = 1; jj < n_own; ++jj)
+                        if (q >= own_tab[jj * OW_WORDS + OW_PRE]) j = jj;
+                    const uint32_t ordinal = count_bits(hitbits, own_tab[j * OW_WORDS + OW_PRE], q);
+                    __builtin_nontemporal_store((uint32_t)pgeom[q] | (ordinal << 8), &rec_point(w)[wi].w);
+                }
+                if (lane < n_own) {
+                    uint32_t* ow = own_tab + lane * OW_WORDS;
+                    ow[OW_RECS] = count_bits(hitbits, ow[OW_PRE], ow[OW_PRE] + ow[OW_N]);
+                }
+                PROF_MARK(7);
                 // ---- every owner continues as many shaded points further on as its children had diffuse hits: the
                 // jumps of all owners at once, one table look-up per (owner, nibble) spread over the lanes, their
                 // images added up in LDS
@@ -1786,7 +1851,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                     const uint32_t o = lane_rank(cm);
                     const uint32_t* ow = own_tab + o * OW_WORDS;
                     const uint32_t recs = ow[OW_RECS];
-                    cnt += ow[OW_SLOTS];
+                    cnt += my_n; // every child has a slot
                     cnt_shade += recs;
                     if (recs != 0u && w.jump_n[0] != 0u) {
                         rng.v0 = acc[o * 5u + 0u];
@@ -2280,6 +2345,7 @@ __global__ void __launch_bounds__(64) wf_sum_kernel(WfArgs w, uint32_t first) {
                 c = contribs[j];
             }
         const uint32_t type = tag & 3u;
+        if (type == TAG_SKIP) continue;
         if (type == TAG_ADD) {
             final_c = final_c + V4{c.x, c.y, c.z, c.w};
         } else if (type == TAG_END_CALL) {
