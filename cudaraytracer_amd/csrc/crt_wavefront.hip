@@ -907,6 +907,7 @@ constexpr uint32_t kCoopSplit = 8;
 constexpr uint32_t kCoopOwners = 64u / kCoopSplit;
 constexpr uint32_t kCoopList = 512; // >= kCoopOwners * kCoopBatch: children one step of a wave can have in its list
 static_assert(kCoopOwners * kCoopBatch <= kCoopList, "list positions");
+static_assert(kCoopOwners <= (1u << (32u - kRecBits)), "a record index and its owner share a word");
 // bits [lo, hi) set in a bit array
 DI uint32_t count_bits(const uint32_t* bits, uint32_t lo, uint32_t hi) {
     uint32_t n = 0;
@@ -1796,7 +1797,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                         if (outcome == 2u && !dark) {
                             const Rng o_rng = Rng{oj[OW_RNG + 0], oj[OW_RNG + 1], oj[OW_RNG + 2], oj[OW_RNG + 3], oj[OW_RNG + 4], oj[OW_RNG + 5]};
                             store_record_body(w, my_wi, c_P, c_N, c_view, r_att, o_rng, (uint32_t)slot);
-                            pend[c_pos] = my_wi < w.cap_work ? my_wi : kNoRecord;
+                            pend[c_pos] = my_wi < w.cap_work ? (my_wi | (c_j << kRecBits)) : kNoRecord; // record and owner (< 8)
                             pgeom[c_pos] = (uint8_t)c_geom;
                         }
                     }
@@ -1812,13 +1813,10 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                 // ---- every child has ended: the records' ordinals (diffuse hits among the earlier children of the same
                 // owner) and, per owner, its number of diffuse hits
                 for (uint32_t q = lane; q < total; q += 64u) {
-                    const uint32_t wi = pend[q];
-                    if (wi == kNoRecord) continue;
-                    uint32_t j = 0;
-                    for (uint32_t jj = 1; jj < n_own; ++jj)
-                        if (q >= own_tab[jj * OW_WORDS + OW_PRE]) j = jj;
-                    const uint32_t ordinal = count_bits(hitbits, own_tab[j * OW_WORDS + OW_PRE], q);
-                    __builtin_nontemporal_store((uint32_t)pgeom[q] | (ordinal << 8), &rec_point(w)[wi].w);
+                    const uint32_t wj = pend[q];
+                    if (wj == kNoRecord) continue;
+                    const uint32_t ordinal = count_bits(hitbits, own_tab[(wj >> kRecBits) * OW_WORDS + OW_PRE], q);
+                    __builtin_nontemporal_store((uint32_t)pgeom[q] | (ordinal << 8), &rec_point(w)[wj & kRecMask].w);
                 }
                 if (lane < n_own) {
                     uint32_t* ow = own_tab + lane * OW_WORDS;

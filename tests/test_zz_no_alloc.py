@@ -100,3 +100,35 @@ def test_static_entry_point_refuses_images_beyond_its_scratch():
             assert err.value.code == abi.CRT_ERR_UNSUPPORTED and "CRT_STATIC_MAX_PIXELS" in str(err.value)
         finally:
             ctx.fb_free(fb)
+
+
+def test_static_calls_from_two_contexts_and_streams_are_queued_one_after_the_other():
+    """Two contexts on one GPU, each with its own stream, call crt_render_static back to back without waiting:
+    the calls share the GPU's scratch array, so the library queues the second behind the first (an event per
+    device).  Both images and RNG end states must be what crt_render gives each context on its own."""
+    import torch
+    sts = [crt.make_settings(nx=96, ny=80, aa_iter=1, gl_iter=1, ind_rays=12, shadowSamples=6),
+           crt.make_settings(nx=64, ny=40, aa_iter=2, gl_iter=1, ind_rays=7, shadowSamples=6)]
+    scene = crt.cornell_box(6)
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    with crt.Context(0) as a, crt.Context(0) as b, crt.Context(0) as ref_ctx:
+        ref_ctx.set_pipeline(abi.CRT_PIPELINE_PERSISTENT)
+        ref_ctx.upload(scene)
+        want = [_render(ref_ctx, st, 40 + k, static=False) for k, st in enumerate(sts)]
+        ctxs = [a, b]
+        fbs = []
+        for k, (ctx, st) in enumerate(zip(ctxs, sts)):
+            ctx.upload(scene)
+            ctx.rng_init(st.nx, st.ny, 40 + k)
+            fbs.append(torch.zeros((st.ny, st.nx, 4), dtype=torch.float32, device=dev))
+        torch.cuda.synchronize(dev)
+        for rep in range(3):  # interleaved, no waiting in between; every repetition renders the same frame again
+            for k, (ctx, st) in enumerate(zip(ctxs, sts)):
+                if rep:
+                    ctx.rng_init(st.nx, st.ny, 40 + k, streams[k].cuda_stream)
+                ctx.render_static(st, fbs[k].data_ptr(), streams[k].cuda_stream)
+        torch.cuda.synchronize(dev)
+        for k, (ctx, st) in enumerate(zip(ctxs, sts)):
+            assert np.array_equal(fbs[k].cpu().numpy(), want[k][0]), f"context {k}: image differs"
+            assert np.array_equal(ctx.rng_export(st.nx, st.ny), want[k][1]), f"context {k}: RNG end states differ"
