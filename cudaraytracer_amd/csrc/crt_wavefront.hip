@@ -99,7 +99,7 @@ struct WfArgs {
     uint32_t* aa_verdict; // [n_lp]: AA_* | all-equal-so-far << 8
     uint32_t* work;
     uint32_t* shadow_cnt;
-    const uint32_t* jump_tabs; // two rng_jump tables: [0] for jump_n[0] = draws per shaded point, [1] for jump_n[1] = 2 ind_rays
+    const uint32_t* jump_tabs; // rng_jump table [0] for jump_n[0] = draws per shaded point (copied to LDS by the trace kernels); [1] unused
     uint32_t jump_n[2];        // 0: no table
     uint32_t* queue;
     uint32_t qchunk;           // queue entries a filter wave reserves at a time (a multiple of 64)
@@ -1283,8 +1283,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                                                                                    uint32_t slot_end) {
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
-    // [0]: the draws of one shaded point; [1] (cooperative kernel only): the 2 ind_rays draws of an expanding hit's children
-    __shared__ __attribute__((aligned(16))) uint32_t s_jump[COOP ? 2 : 1][kJumpWords];
+    __shared__ __attribute__((aligned(16))) uint32_t s_jump[1][kJumpWords]; // the draws of one shaded point
     // one row per primitive of the scene (dynamic, sized by the launch): with the two jump tables the workgroup
     // stays under 32 KB for scenes of up to 49 primitives, so that five workgroups fit a CU's LDS
     __shared__ uint32_t s_coop[COOP ? kTraceWaves : 1u][COOP ? kCoopOwners * OW_WORDS : 1u];
@@ -1294,8 +1293,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
     __shared__ uint32_t s_hitbits[COOP ? kTraceWaves : 1u][COOP ? kCoopList / 32u : 1u];
     extern __shared__ __attribute__((aligned(16))) float s_prim_words[];
     PrimRow* s_prim = reinterpret_cast<PrimRow*>(s_prim_words);
-    for (uint32_t k = threadIdx.x; k < (COOP ? 2u : 1u) * kJumpWords; k += 64u * kTraceWaves)
-        s_jump[k / kJumpWords][k % kJumpWords] = w.jump_tabs[k];
+    for (uint32_t k = threadIdx.x; k < kJumpWords; k += 64u * kTraceWaves) s_jump[0][k] = w.jump_tabs[k];
     fill_prim_table(sc, s_prim, threadIdx.x, 64u * kTraceWaves);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -1592,45 +1590,26 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                 if (skip_draws != 0u && skip_draws == w.jump_n[0]) rng_jump(rng, s_jump[0], skip_draws * 362437u);
                 else for (uint32_t k = 0; k < skip_draws; ++k) rng_step(rng);
 #endif
-                if (COOP && n_depth > 0u) {
-                    PROF_LANES(13);
-                    ++cnt_expand;
-                    // The reference draws (r1,r2) for every child and pushes while its stack has room (main.cu:176-191).
-                    uint32_t room = on_stack < CRT_RAY_STACK ? CRT_RAY_STACK - on_stack : 0u;
-                    uint32_t accepted = a.ind_rays < room ? a.ind_rays : room;
-                    if (n_depth == 1u) {
-                        // leaf children: keep their draws where any lane of the wave can pick them up
-                        for (uint32_t k = 0; k < 2u * accepted; ++k) w.draws[(size_t)k * n_lp + lp] = rng_uniform(rng);
-                    } else if (accepted != 0u && 2u * accepted == w.jump_n[1]) {
-                        rng_jump(rng, s_jump[COOP ? 1 : 0], 2u * accepted * 362437u);
-                    } else {
-                        for (uint32_t k = 0; k < 2u * accepted; ++k) rng_step(rng);
-                    }
-                    if (accepted > 0u) {
-                        uint4* f = frame_at(w, nframes, lp);
-                        ++nframes;
-                        f[FG_POINT * n_lp] = make_uint4(f2u(n_P.x), f2u(n_P.y), f2u(n_P.z), n_geom);
-                        f[FG_NORMAL * n_lp] = make_uint4(f2u(n_N.x), f2u(n_N.y), f2u(n_N.z), n_depth - 1u);
-                        f[FG_ATT * n_lp] = make_uint4(f2u(n_att.x), f2u(n_att.y), f2u(n_att.z), f2u(n_att.w));
-                        f[FG_GEN * n_lp] = make_uint4(rng.v0, rng.v1, rng.v2, rng.v3);
-                        f[FG_GEN2 * n_lp] = make_uint4(rng.v4, rng.d, accepted, 0u);
-                        on_stack += accepted;
-                    }
-                    for (uint32_t k = 2u * accepted; k < 2u * a.ind_rays; ++k) rng_step(rng);
-                }
             }
-            if (!COOP) {
+            {
                 // ---- expanding hits: the reference draws (r1,r2) for every one of the ind_rays children and pushes
                 // while its stack has room (main.cu:176-191).  The frame keeps the generator state behind the draws of
-                // the `accepted` children it holds (they are stepped back out of it one by one), the pixel goes on
-                // behind all 2 ind_rays draws.  Both are jumps of one lane's state, made by the whole wave.
+                // the `accepted` children it holds (the per-pixel kernel steps them back out of it one by one), the
+                // pixel goes on behind all 2 ind_rays draws.  Both are jumps of one lane's state, made by the whole wave.
+                // The cooperative kernel needs the draws of a leaf node's children as numbers (its lanes pick them up
+                // from w.draws): those it steps through, and jumps only over the draws of the children that found no room.
                 const bool push = emit && n_depth > 0u;
-                uint32_t accepted = 0;
+                uint32_t accepted = 0, to_jump = 0; // children kept; of those, the ones whose draws are still to be jumped over
                 if (push) {
                     PROF_LANES(13);
                     ++cnt_expand;
                     const uint32_t room = on_stack < CRT_RAY_STACK ? CRT_RAY_STACK - on_stack : 0u;
                     accepted = a.ind_rays < room ? a.ind_rays : room;
+                    to_jump = accepted;
+                    if (COOP && n_depth == 1u) {
+                        for (uint32_t k = 0; k < 2u * accepted; ++k) w.draws[(size_t)k * n_lp + lp] = rng_uniform(rng);
+                        to_jump = 0u;
+                    }
                 }
                 Rng fgen = rng; // generator state the frame keeps
                 for (uint64_t pmask = __ballot(push); pmask != 0ull; pmask &= pmask - 1ull) {
@@ -1638,19 +1617,20 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                     uint32_t v[5] = {(uint32_t)__builtin_amdgcn_readlane((int)rng.v0, src), (uint32_t)__builtin_amdgcn_readlane((int)rng.v1, src),
                                      (uint32_t)__builtin_amdgcn_readlane((int)rng.v2, src), (uint32_t)__builtin_amdgcn_readlane((int)rng.v3, src),
                                      (uint32_t)__builtin_amdgcn_readlane((int)rng.v4, src)};
-                    const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)accepted, src);
+                    const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)to_jump, src);
+                    const uint32_t rest = a.ind_rays - (uint32_t)__builtin_amdgcn_readlane((int)accepted, src);
                     for (uint32_t left = acc; left != 0u;) { // (more children than tables: ind_rays above CRT_RAY_STACK never are accepted)
                         const uint32_t n = left < w.draw_tabs_n ? left : w.draw_tabs_n;
                         wave_jump(v, w.draw_tabs + (size_t)(n - 1u) * kJumpWords, lane);
                         left -= n;
                     }
                     if (lane == (uint32_t)src) fgen = Rng{v[0], v[1], v[2], v[3], v[4], rng.d + 2u * acc * 362437u};
-                    for (uint32_t left = a.ind_rays - acc; left != 0u;) {
+                    for (uint32_t left = rest; left != 0u;) {
                         const uint32_t n = left < w.draw_tabs_n ? left : w.draw_tabs_n;
                         wave_jump(v, w.draw_tabs + (size_t)(n - 1u) * kJumpWords, lane);
                         left -= n;
                     }
-                    if (lane == (uint32_t)src) rng = Rng{v[0], v[1], v[2], v[3], v[4], rng.d + 2u * a.ind_rays * 362437u};
+                    if (lane == (uint32_t)src) rng = Rng{v[0], v[1], v[2], v[3], v[4], rng.d + 2u * (acc + rest) * 362437u};
                 }
                 if (push && accepted > 0u) {
                     uint4* f = frame_at(w, nframes, lp);
@@ -2930,7 +2910,7 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
 
     // generator jump tables for this scene and these settings
     {
-        const uint32_t want[2] = {2u * args.max_shadow_rays, args.gl_iter ? 2u * args.ind_rays : 0u};
+        const uint32_t want[2] = {2u * args.max_shadow_rays, 0u}; // (the children's draws are jumped with draw_tabs)
         for (int t = 0; t < 2; ++t) {
             if (ws.jump_n[t] == want[t]) continue;
             std::vector<uint32_t> tab(kJumpWords, 0u);
@@ -2943,9 +2923,9 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         }
         w.jump_n[0] = ws.jump_n[0];
         w.jump_n[1] = ws.jump_n[1];
-        // per-pixel trace kernel: one table per number of children an expanding hit can keep, 2a draws each
+        // one table per number of children an expanding hit can keep, 2a draws each
         const uint32_t n_child_tabs = args.gl_iter == 0u ? 0u : (args.ind_rays < CRT_RAY_STACK ? args.ind_rays : CRT_RAY_STACK);
-        if (n_child_tabs != 0u && n_coop != args.n_units && (ws.draw_tabs_n != n_child_tabs || !ws.draw_tabs)) {
+        if (n_child_tabs != 0u && (ws.draw_tabs_n != n_child_tabs || !ws.draw_tabs)) {
             if (ws.draw_tabs) {
                 e = hipStreamSynchronize(stream);
                 if (e != hipSuccess) return e;
