@@ -61,8 +61,8 @@ struct WfWorkspace {
     uint32_t* work = nullptr;       // shade records: cap_work x WF_WORK_PLANES words, in six arrays of 16-byte groups
     uint32_t* shadow_cnt = nullptr; // [n_lights][cap_work]
     uint32_t* queue = nullptr;      // [3][qcap]
-    uint32_t* jump_dev = nullptr;   // two generator jump tables
-    uint32_t jump_n[2] = {0, 0};    // step counts the tables were built for
+    uint32_t* jump_dev = nullptr;   // generator jump table: the draws of one shaded point
+    uint32_t jump_n[1] = {0};       // step count the table was built for
     uint32_t* unit_cost = nullptr;  // [n_units] cost estimate per work unit (float bits)
     uint32_t* unit_order = nullptr; // [n_units] launch order of the trace kernel
     uint32_t* unit_host = nullptr;  // pinned: [n_units] costs, then [n_units] order

@@ -99,8 +99,8 @@ struct WfArgs {
     uint32_t* aa_verdict; // [n_lp]: AA_* | all-equal-so-far << 8
     uint32_t* work;
     uint32_t* shadow_cnt;
-    const uint32_t* jump_tabs; // rng_jump table [0] for jump_n[0] = draws per shaded point (copied to LDS by the trace kernels); [1] unused
-    uint32_t jump_n[2];        // 0: no table
+    const uint32_t* jump_tabs; // rng_jump table for jump_n[0] = the draws of one shaded point (copied to LDS by the trace kernels)
+    uint32_t jump_n[1];        // 0: no table
     uint32_t* queue;
     uint32_t qchunk;           // queue entries a filter wave reserves at a time (a multiple of 64)
     const uint32_t* unit_order; // trace: launch slot -> work unit, most expensive first; null = identity
@@ -2606,7 +2606,7 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     grab((void**)&ws.work, (size_t)WF_WORK_PLANES * cap_work * 4u);
     grab((void**)&ws.shadow_cnt, (size_t)lights * cap_work * 4u);
     grab((void**)&ws.queue, (size_t)3u * qcap * 4u);
-    grab((void**)&ws.jump_dev, (size_t)2u * kJumpWords * 4u);
+    grab((void**)&ws.jump_dev, (size_t)kJumpWords * 4u);
     grab((void**)&ws.backup, ((size_t)8u * npix + 8u) * 4u);
     grab((void**)&ws.unit_cost, (size_t)args.n_units * 4u);
     grab((void**)&ws.unit_order, (size_t)args.n_units * 4u);
@@ -2860,7 +2860,6 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     w.queue = ws.queue;
     w.jump_tabs = ws.jump_dev;
     w.jump_n[0] = ws.jump_n[0];
-    w.jump_n[1] = ws.jump_n[1];
     w.draws = ws.draws;
     w.coop_tabs = ws.coop_tabs;
     w.draw_tabs = ws.draw_tabs;
@@ -2910,8 +2909,8 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
 
     // generator jump tables for this scene and these settings
     {
-        const uint32_t want[2] = {2u * args.max_shadow_rays, 0u}; // (the children's draws are jumped with draw_tabs)
-        for (int t = 0; t < 2; ++t) {
+        const uint32_t want[1] = {2u * args.max_shadow_rays};
+        for (int t = 0; t < 1; ++t) {
             if (ws.jump_n[t] == want[t]) continue;
             std::vector<uint32_t> tab(kJumpWords, 0u);
             if (want[t] != 0u) build_jump_table(want[t], tab.data());
@@ -2922,7 +2921,6 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
             ws.jump_n[t] = want[t];
         }
         w.jump_n[0] = ws.jump_n[0];
-        w.jump_n[1] = ws.jump_n[1];
         // one table per number of children an expanding hit can keep, 2a draws each
         const uint32_t n_child_tabs = args.gl_iter == 0u ? 0u : (args.ind_rays < CRT_RAY_STACK ? args.ind_rays : CRT_RAY_STACK);
         if (n_child_tabs != 0u && (ws.draw_tabs_n != n_child_tabs || !ws.draw_tabs)) {
