@@ -29,6 +29,7 @@ sys.path.insert(0, str(ROOT))
 # README.md:131-134 of the reference (RTX 4070 Ti SUPER), seconds per render
 README_4070TIS_S = {"gl0": 0.116, "gl1": 10.438, "gl2": 574.214, "gl3": 23040.602}
 PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak (needs packed v_pk_fma_f32; see peak_note)
+PEAK_HBM_TBPS = 8.0       # MI355X HBM3E
 
 
 def algorithmic_flops(stats):
@@ -361,11 +362,23 @@ def main():
         per_launch = {k: v / args.steps for k, v in work.items()}
         achieved = algorithmic_flops(per_launch) / (kernel_ms * 1e-3) / 1e12
         traffic = traffic_from = None
+        per_kernel = per_kernel_roofline(ktimes, per_launch)
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():  # PMC passes are separate rocprofv3 runs (tools/prof_traffic.sh); the line quotes their result
             try:
                 entry = json.loads(tfile.read_text()).get(f"{args.workload}_n{world}_{nx}x{ny}", {})
                 traffic, traffic_from = entry.get("hbm_bytes_per_launch"), entry.get("profile")
+                # the profiled bytes of each kernel over this run's time for it: which kernels the memory side bounds
+                pk = entry.get("per_kernel", {})
+                names = {"trace": ["wf_trace_kernel"], "filter+resolve": ["wf_filter_kernel", "wf_resolve_kernel"],
+                         "shade": ["wf_shade_kernel"], "sum": ["wf_sum_kernel"]}
+                for k, kernels in names.items():
+                    nbytes = sum(pk.get(n, {}).get("hbm_bytes_upper", 0.0) for n in kernels)
+                    ms = per_kernel.get(k, {}).get("ms") or (ktimes.get(k, (0, 0))[0] if k in ktimes else 0)
+                    if nbytes and ms:
+                        per_kernel.setdefault(k, {"ms": ms})
+                        per_kernel[k].update({"hbm_gb_profiled": nbytes / 1e9, "hbm_tbps": nbytes / (ms * 1e-3) / 1e12,
+                                              "hbm_frac": nbytes / (ms * 1e-3) / 1e12 / PEAK_HBM_TBPS})
             except Exception:
                 traffic = None
         out = {
@@ -391,10 +404,12 @@ def main():
                          "kernel": ("wavefront pipeline (" + "+".join(ktimes) + ")") if ktimes else "crt::render_kernel",
                          "kernel_ms": kernel_ms, "render_call_ms": render_ms,
                          "kernels": {k: {"ms": ms, "launches": n} for k, (ms, n) in ktimes.items()},
-                         "per_kernel": per_kernel_roofline(ktimes, per_launch),
+                         "per_kernel": per_kernel,
                          "per_kernel_note": "model FLOPs by the kernel that does them: trace 450*shade_points + 40*gi_children, "
                                             "filter+resolve 300*shadow_samples (97.8 % of the rays are decided by conservative "
-                                            "tests that cost a fraction of the exact test they stand for), shade 750*shade_points",
+                                            "tests that cost a fraction of the exact test they stand for), shade 750*shade_points; "
+                                            "hbm_*: the profile's bytes for the kernel (upper bound, see traffic_profile) over this "
+                                            "run's time for it, against 8 TB/s",
                          "peak_note": "157.3 = 256 CU x 4 SIMD x 16 lanes/clk x 2 (packed v_pk_fma_f32) x 2 flop x 2.4 GHz; "
                                       "a plain wave64 VALU instruction issues every 4 cycles per SIMD (78.6 TFLOP/s for unpacked fma)",
                          "flops_model": "300*shadow_samples + 1200*shade_points + 40*gi_children (rank 0's launch)"},
