@@ -176,6 +176,56 @@ def config5(args, torch, crt):
     }), flush=True)
 
 
+def two_in_flight(torch, crt, ctx, st, dev, seed, frames):
+    """Throughput of a host that renders independent frames: two contexts on one GPU, each with its own stream and
+    host thread, so that one frame's trace kernel runs next to the other's filter, resolve and shade kernels.  Not the
+    headline figure (that is one frame's render time); it says what the GPU has left while a single frame runs."""
+    import threading
+    ctx2 = crt.Context(dev.index)
+    try:
+        ctx2.upload(crt.cornell_box(st.shadowSamples))
+        ctx2.rng_init(st.nx, st.ny, seed + 1)
+        ctx2.reserve_workspace(st, 0, 1)
+        fbs = [torch.empty((st.ny, st.nx, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        gate = threading.Barrier(3)
+        errors = []
+
+        def run(k, c):
+            try:
+                c.render(st, fbs[k].data_ptr(), streams[k].cuda_stream)  # warm-up
+                streams[k].synchronize()
+                gate.wait()
+                for _ in range(frames):
+                    c.render(st, fbs[k].data_ptr(), streams[k].cuda_stream)
+                streams[k].synchronize()
+            except Exception as e:
+                errors.append(e)
+                gate.abort()
+                return
+            gate.wait()
+
+        threads = [threading.Thread(target=run, args=(k, c)) for k, c in enumerate((ctx, ctx2))]
+        for t in threads:
+            t.start()
+        dt = None
+        try:
+            gate.wait()
+            t0 = time.perf_counter()
+            gate.wait()
+            dt = (time.perf_counter() - t0) / (2 * frames)
+        except threading.BrokenBarrierError:
+            pass
+        for t in threads:
+            t.join()
+        if errors or dt is None:
+            raise errors[0] if errors else RuntimeError("a render thread gave up")
+        return {"ms_per_frame": dt * 1e3, "frames": 2 * frames,
+                "note": "two contexts, streams and host threads on one GPU, independent frames; throughput, not render time"}
+    finally:
+        ctx2.close()
+
+
 def launch_ranks(n):
     """Re-runs this command line as n ranks under torch.distributed.run and returns their exit status.
     The parent has made no HIP call, so the children are the only processes on the GPUs."""
@@ -460,6 +510,10 @@ def main():
                                                "kernels": {k: {"ms": ms, "launches": n} for k, (ms, n) in kt.items()},
                                                "per_kernel": per_kernel_roofline(kt, w2), "work_per_frame": w2}
             out["readme_rows"] = rows
+            try:
+                out["two_frames_in_flight"] = two_in_flight(torch, crt, ctx, st, dev, args.seed, min(args.steps, 10))
+            except Exception as e:  # a side figure: never lose the line over it
+                out["two_frames_in_flight"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(gl, 20.0)
         print(json.dumps(out), flush=True)
