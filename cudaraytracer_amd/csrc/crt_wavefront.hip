@@ -2274,7 +2274,12 @@ DI void shade_record(const WfArgs& w, ScenePtr sc, uint32_t wi) {
         }
     }
     const V4 c = att * direct; // final_color += attenuation * light (main.cu:195)
+#ifdef CRT_ABLATE_SCATTER // measuring aid (wrong image): results stored in record order, what the kernel takes without the permutation
+    const size_t n_slots = (size_t)w.quota * w.n_lp;
+    w.contrib[wi < n_slots ? wi : slot] = make_float4(c.x, c.y, c.z, c.w);
+#else
     w.contrib[slot] = make_float4(c.x, c.y, c.z, c.w);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ sum
