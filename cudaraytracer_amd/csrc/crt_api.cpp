@@ -51,6 +51,12 @@ struct crt_ctx {
     int coop_permille = -1; // CRT_COOP_PERMILLE as read by crt_create (tools/mix_sweep.sh); -1: by launch size
     size_t workspace_limit = (size_t)96 << 30;
     crt::WfWorkspace wf;
+    // Launches of one context share its generator states, work counters and workspace, so they run one after the
+    // other whatever streams they are given: every launch records `last_done` behind itself, and a call on another
+    // stream than the previous one first makes its stream wait for that event.
+    hipEvent_t last_done = nullptr;
+    void* last_stream = nullptr;
+    bool launched = false;
 };
 
 namespace {
@@ -73,6 +79,18 @@ int fail(crt_ctx* ctx, int code, const char* fmt, ...) {
 
 int bind(crt_ctx* ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return CRT_OK;
+}
+
+int order_behind_last_launch(crt_ctx* ctx, hipStream_t stream) {
+    if (ctx->launched && ctx->last_stream != (void*)stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->last_done, 0));
+    return CRT_OK;
+}
+
+int mark_launched(crt_ctx* ctx, hipStream_t stream) {
+    HIP_TRY(ctx, hipEventRecord(ctx->last_done, stream));
+    ctx->last_stream = (void*)stream;
+    ctx->launched = true;
     return CRT_OK;
 }
 
@@ -147,7 +165,7 @@ hipError_t reserve_workspace(crt_ctx* ctx, const crt::RenderArgs& a) {
 }
 
 // Runs one launch through the pipeline the context selects.
-int run_render(crt_ctx* ctx, const crt::RenderArgs& args, hipStream_t stream) {
+int run_pipeline(crt_ctx* ctx, const crt::RenderArgs& args, hipStream_t stream) {
     crt::RenderArgs a = args;
     a.cooperative = pick_cooperative(ctx, a);
     const bool can_wf = crt::wavefront_supports(a);
@@ -174,6 +192,14 @@ int run_render(crt_ctx* ctx, const crt::RenderArgs& args, hipStream_t stream) {
         return fail(ctx, CRT_ERR_TRUNCATED, "frame stopped after %u rounds (crt_set_round_limit): image unfinished, RNG states mid-tree",
                     ctx->wf.max_rounds);
     return CRT_OK;
+}
+
+int run_render(crt_ctx* ctx, const crt::RenderArgs& args, hipStream_t stream) {
+    int rc = order_behind_last_launch(ctx, stream);
+    if (rc != CRT_OK) return rc;
+    rc = run_pipeline(ctx, args, stream);
+    const int marked = mark_launched(ctx, stream); // also after a failure: part of the launch may be queued
+    return rc != CRT_OK ? rc : marked;
 }
 
 } // namespace
@@ -214,6 +240,11 @@ int crt_create(crt_ctx** out, int device) {
         crt_destroy(ctx);
         return CRT_ERR_HIP;
     }
+    if (hipEventCreateWithFlags(&ctx->last_done, hipEventDisableTiming) != hipSuccess) {
+        ctx->last_done = nullptr;
+        crt_destroy(ctx);
+        return CRT_ERR_HIP;
+    }
     if (crt::prime_render_grid() != hipSuccess) {
         crt_destroy(ctx);
         return CRT_ERR_HIP;
@@ -233,6 +264,7 @@ void crt_destroy(crt_ctx* ctx) {
         (void)hipFree(ctx->rng_init_d);
         (void)hipFree(ctx->counters_dev);
         (void)hipFree(ctx->unit_counter);
+        if (ctx->last_done) (void)hipEventDestroy(ctx->last_done);
         crt::wavefront_release(ctx->wf);
     }
     delete ctx;
@@ -279,13 +311,14 @@ int crt_rng_init(crt_ctx* ctx, uint32_t nx, uint32_t ny, uint64_t seed, void* st
         ctx->rng_ny = ny;
     }
     hipStream_t s = (hipStream_t)stream;
+    if ((rc = order_behind_last_launch(ctx, s)) != CRT_OK) return rc; // a frame still running elsewhere draws from these states
     crt::launch_random_init((uint32_t)npix, seed, ctx->rng_dev, s);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->rng_init_d, ctx->rng_dev + 5 * npix, npix * sizeof(uint32_t),
                                 hipMemcpyDeviceToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->counters_dev, 0, npix * 2 * sizeof(uint32_t), s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->unit_counter + 16, 0, 32, s));
-    return CRT_OK;
+    return mark_launched(ctx, s);
 }
 
 int crt_rng_export(crt_ctx* ctx, uint32_t* host_state6) {
@@ -341,13 +374,14 @@ int crt_render_static(crt_ctx* ctx, const crt_settings* st, float* fb_dev, void*
     a.audit = 0u;
     // the previous call on this GPU may still be using the array on another stream: queue behind it
     const int dv = ctx->device;
+    if ((rc = order_behind_last_launch(ctx, (hipStream_t)stream)) != CRT_OK) return rc;
     if (g_static_used[dv] && g_static_stream[dv] != stream) HIP_TRY(ctx, hipStreamWaitEvent((hipStream_t)stream, g_static_done[dv], 0));
     HIP_TRY(ctx, hipMemsetAsync(sp, 0, (CRT_STATIC_HEAD_WORDS + 2u * npix) * sizeof(uint32_t), (hipStream_t)stream));
     HIP_TRY(ctx, crt::launch_render(a, (hipStream_t)stream));
     HIP_TRY(ctx, hipEventRecord(g_static_done[dv], (hipStream_t)stream));
     g_static_stream[dv] = stream;
     g_static_used[dv] = true;
-    return CRT_OK;
+    return mark_launched(ctx, (hipStream_t)stream);
 }
 
 int crt_render_partial(crt_ctx* ctx, const crt_settings* st, uint32_t tileIndex, float* fb_dev, void* stream) {

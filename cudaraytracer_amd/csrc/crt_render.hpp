@@ -125,6 +125,9 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
 // Looks at the counter copies of frames that were left running: with `wait` the call waits for them, without
 // it takes those that have landed.  Returns true (once) if one of them had raised a device flag.
 bool wavefront_collect_async(WfWorkspace& ws, bool wait);
+// Orders `stream` behind the frames that were left running on another stream: they share the context's generator
+// states, work counters and workspace with whatever the caller queues next.
+hipError_t wavefront_order_behind_async(WfWorkspace& ws, hipStream_t stream);
 
 void launch_random_init(uint32_t npix, uint64_t seed, uint32_t* state, hipStream_t stream);
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream);

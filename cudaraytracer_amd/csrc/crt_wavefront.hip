@@ -2557,6 +2557,19 @@ bool wavefront_collect_async(WfWorkspace& ws, bool wait) {
     return bad;
 }
 
+// Frames left running on another stream share this context's workspace, counters and generator states: what is
+// queued on `stream` next is ordered behind the latest of them.  (Frames that returned after their last round have
+// been waited for.)
+hipError_t wavefront_order_behind_async(WfWorkspace& ws, hipStream_t stream) {
+    if (ws.async_pending != 0u && ws.last_stream != (void*)stream && ws.round_events) {
+        const uint32_t latest = (ws.async_next + WF_CTR_RING - 1u) % WF_CTR_RING;
+        const hipError_t e = hipStreamWaitEvent(stream, static_cast<hipEvent_t*>(ws.round_events)[latest], 0);
+        if (e != hipSuccess) return e;
+    }
+    ws.last_stream = (void*)stream;
+    return hipSuccess;
+}
+
 hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n_lights, size_t budget_bytes) {
     const uint32_t n_lp = args.n_units * 64u;
     if (n_lp == 0) return hipSuccess;
@@ -2828,14 +2841,8 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     }
     const uint32_t cus = (uint32_t)g_resident_cus[dev];
     if (ws.npix != args.nx * args.ny) return hipErrorInvalidValue; // wavefront_reserve was given another image
-    // Frames left running on another stream share this context's workspace, counters and generator states: this
-    // launch is ordered behind the latest of them.  (Frames that returned after their last round have been waited for.)
-    if (ws.async_pending != 0u && ws.last_stream != (void*)stream) {
-        const uint32_t latest = (ws.async_next + WF_CTR_RING - 1u) % WF_CTR_RING;
-        e = hipStreamWaitEvent(stream, static_cast<hipEvent_t*>(ws.round_events)[latest], 0);
-        if (e != hipSuccess) return e;
-    }
-    ws.last_stream = (void*)stream;
+    e = wavefront_order_behind_async(ws, stream);
+    if (e != hipSuccess) return e;
 
     WfArgs w;
     w.r = args;

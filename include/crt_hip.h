@@ -12,7 +12,11 @@
  *
  * Threading: a crt_ctx belongs to one host thread and one GPU.  Work is queued
  * on the HIP stream handed to each call (NULL = the default stream); calls do
- * not synchronise unless their comment says so.
+ * not synchronise unless their comment says so.  The launches of one context
+ * (crt_rng_init and the crt_render* calls) share its RNG states and work
+ * counters, so the library runs them one after the other: a call on another
+ * stream than the context's previous launch is queued behind that launch (an
+ * event per context).  Buffers the caller owns are the caller's to order.
  *
  * Memory: "dev" pointers are device (HBM) addresses owned by the caller;
  * "host" pointers are ordinary host memory.  The context owns the flattened

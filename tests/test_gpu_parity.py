@@ -83,6 +83,33 @@ def test_second_render_continues_streams(gpu_ctx, oracle):
     assert np.array_equal(gpu_ctx.rng_export(32, 32), s2)
 
 
+def test_calls_on_another_stream_are_ordered_behind_frames_left_running(gpu_ctx, oracle):
+    """A gl_iter 0 frame is left running on its stream when crt_render returns.  Re-seeding and rendering on a second
+    stream right away, without waiting, must not race with it: both share the context's generator states."""
+    import torch
+    dev = torch.device("cuda", 0)
+    st = crt.make_settings(nx=256, ny=192, aa_iter=1, gl_iter=0, shadowSamples=16)
+    gpu_ctx.upload(crt.cornell_box(16))
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    fb1 = torch.zeros((st.ny, st.nx, 4), dtype=torch.float32, device=dev)
+    fb2 = torch.zeros_like(fb1)
+    torch.cuda.synchronize(dev)
+    gpu_ctx.rng_init(st.nx, st.ny, 21, s1.cuda_stream)
+    for _ in range(3):  # three frames from seed 21, back to back on the first stream
+        gpu_ctx.render(st, fb1.data_ptr(), s1.cuda_stream)
+    gpu_ctx.rng_init(st.nx, st.ny, 22, s2.cuda_stream)  # no wait in between
+    gpu_ctx.render(st, fb2.data_ptr(), s2.cuda_stream)
+    torch.cuda.synchronize(dev)
+    osc = oracle.cornell(16)
+    state = None
+    for _ in range(3):
+        want1, _, state = oracle.render(osc, st, 21, rng_state=state, want_state=True)
+    want2, _, state2 = oracle.render(osc, st, 22, want_state=True)
+    assert np.array_equal(fb1.cpu().numpy(), want1), "third frame of the first stream differs"
+    assert np.array_equal(fb2.cpu().numpy(), want2), "frame of the second stream differs"
+    assert np.array_equal(gpu_ctx.rng_export(st.nx, st.ny), state2)
+
+
 def test_fast_reciprocal_is_correctly_rounded(gpu_ctx):
     """The kernels' reciprocal (hardware estimate + two fused Newton steps) must equal the IEEE
     quotient 1.0f/x for every one of the 2^32 float bit patterns."""
