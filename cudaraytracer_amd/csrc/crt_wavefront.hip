@@ -954,6 +954,38 @@ DI void wave_jump(uint32_t (&v)[5], const uint32_t* tab, uint32_t lane) {
     v[4] = wave_xor(q4);
 }
 
+// rng_jump with the state cut into 32 chunks of five bits instead of 40 of four: 32 look-ups per jump, a table of
+// 32 x 32 entries (20 KB, what a trace workgroup's LDS has room for next to the primitive table).  Entry
+// e = chunk * 32 + value: words 0..3 at tab[4e .. 4e+3], word 4 at tab[4 * 1024 + e]; chunk c is bits [5c, 5c+5) of
+// the 160-bit string v0 | v1 << 32 | ..., four of the chunks straddle two words.
+#ifndef CRT_JUMP5
+#define CRT_JUMP5 1
+#endif
+constexpr uint32_t kJump5Entries = 32u * 32u, kJump5Words = 5u * kJump5Entries;
+constexpr uint32_t kTraceJumpWords = CRT_JUMP5 ? kJump5Words : kJumpWords; // the table the trace kernels keep in LDS
+DI void rng_jump5(Rng& s, const uint32_t* tab, uint32_t weyl_step) {
+    const uint32_t in[6] = {s.v0, s.v1, s.v2, s.v3, s.v4, 0u};
+    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+    const uint4* tab4 = reinterpret_cast<const uint4*>(tab);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        const int wd = (5 * c) >> 5, sh = (5 * c) & 31;
+        const uint32_t bits = sh <= 27 ? in[wd] >> sh : __builtin_amdgcn_alignbit(in[wd + 1], in[wd], (uint32_t)sh);
+        const uint32_t idx = (uint32_t)c * 32u + (bits & 31u);
+        const uint4 q = tab4[idx];
+        o0 ^= q.x;
+        o1 ^= q.y;
+        o2 ^= q.z;
+        o3 ^= q.w;
+        o4 ^= tab[4u * kJump5Entries + idx];
+        // the sums are made here, not folded into whatever uses the state next: without this (and with it behind the
+        // loop instead of in its last pass) the compiler keeps the 32 look-ups' results alive past the jump, 128
+        // registers and spills instead of 95
+        if (c == 31) asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4));
+    }
+    s = Rng{o0, o1, o2, o3, o4, s.d + weyl_step};
+}
+
 // Children of the innermost frame leave last-to-first (main.cu:176-191 pushes, :132 pops):
 // get_random_ray_values_in_hemisphere (main.cu:60-74) and the child's attenuation (main.cu:186).
 DI void child_ray(V3 hp, V3 hn, V4 patt, V4 pdiff, float r1, float r2, float inv_ind, V3& o, V3& d, V4& att) {
@@ -1283,7 +1315,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
                                                                                    uint32_t slot_end) {
     const RenderArgs& a = w.r;
     ScenePtr sc = (ScenePtr)a.scene;
-    __shared__ __attribute__((aligned(16))) uint32_t s_jump[1][kJumpWords]; // the draws of one shaded point
+    __shared__ __attribute__((aligned(16))) uint32_t s_jump[1][kTraceJumpWords]; // the draws of one shaded point
     // one row per primitive of the scene (dynamic, sized by the launch): with the two jump tables the workgroup
     // stays under 32 KB for scenes of up to 49 primitives, so that five workgroups fit a CU's LDS
     __shared__ uint32_t s_coop[COOP ? kTraceWaves : 1u][COOP ? kCoopOwners * OW_WORDS : 1u];
@@ -1293,7 +1325,7 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
     __shared__ uint32_t s_hitbits[COOP ? kTraceWaves : 1u][COOP ? kCoopList / 32u : 1u];
     extern __shared__ __attribute__((aligned(16))) float s_prim_words[];
     PrimRow* s_prim = reinterpret_cast<PrimRow*>(s_prim_words);
-    for (uint32_t k = threadIdx.x; k < kJumpWords; k += 64u * kTraceWaves) s_jump[0][k] = w.jump_tabs[k];
+    for (uint32_t k = threadIdx.x; k < kTraceJumpWords; k += 64u * kTraceWaves) s_jump[0][k] = w.jump_tabs[k];
     fill_prim_table(sc, s_prim, threadIdx.x, 64u * kTraceWaves);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -1587,7 +1619,10 @@ __global__ void CRT_TRACE_WAVES_ATTR __launch_bounds__(64 * kTraceWaves, COOP ? 
 #ifdef CRT_ABLATE_JUMP
                 rng.d += skip_draws * 362437u; rng.v0 ^= rng.v1 + rng.d;
 #else
-                if (skip_draws != 0u && skip_draws == w.jump_n[0]) rng_jump(rng, s_jump[0], skip_draws * 362437u);
+                if (skip_draws != 0u && skip_draws == w.jump_n[0]) {
+                    if (CRT_JUMP5) rng_jump5(rng, s_jump[0], skip_draws * 362437u);
+                    else rng_jump(rng, s_jump[0], skip_draws * 362437u);
+                }
                 else for (uint32_t k = 0; k < skip_draws; ++k) rng_step(rng);
 #endif
             }
@@ -2461,6 +2496,26 @@ void compose_jump_tables(const uint32_t* a, const uint32_t* b, uint32_t* out) {
     }
 }
 
+// The five-bit form of a jump table (rng_jump5): every chunk value, as a generator state, put through the nibble table.
+void regroup_jump_table5(const uint32_t* nib, uint32_t* out) {
+    for (uint32_t c = 0; c < 32u; ++c)
+        for (uint32_t val = 0; val < 32u; ++val) {
+            uint32_t in[5] = {0, 0, 0, 0, 0};
+            for (uint32_t b = 0; b < 5u; ++b)
+                if ((val >> b) & 1u) in[(5u * c + b) >> 5] |= 1u << ((5u * c + b) & 31u);
+            uint32_t o[5] = {0, 0, 0, 0, 0};
+            for (uint32_t wd = 0; wd < 5u; ++wd)
+                for (uint32_t nb = 0; nb < 8u; ++nb) {
+                    const uint32_t idx = (wd * 8u + nb) * 16u + ((in[wd] >> (4u * nb)) & 15u);
+                    for (uint32_t k = 0; k < 4u; ++k) o[k] ^= nib[4u * idx + k];
+                    o[4] ^= nib[4u * kJumpEntries + idx];
+                }
+            const uint32_t e = c * 32u + val;
+            for (uint32_t k = 0; k < 4u; ++k) out[4u * e + k] = o[k];
+            out[4u * kJump5Entries + e] = o[4];
+        }
+}
+
 // Result slots one pixel can fill without a break: per color() call one per popped ray that can end in a hit
 // or a miss (1 + ind + ind^2 + ..) and one end-of-call marker; one end-of-pixel marker.  Without a break a
 // pixel makes 1 (aa_iter 0) or 4 (aa_iter 1) color() calls, else a level-2 task's four subtasks of four calls
@@ -2624,7 +2679,7 @@ hipError_t wavefront_reserve(WfWorkspace& ws, const RenderArgs& args, uint32_t n
     grab((void**)&ws.work, (size_t)WF_WORK_PLANES * cap_work * 4u);
     grab((void**)&ws.shadow_cnt, (size_t)lights * cap_work * 4u);
     grab((void**)&ws.queue, (size_t)3u * qcap * 4u);
-    grab((void**)&ws.jump_dev, (size_t)kJumpWords * 4u);
+    grab((void**)&ws.jump_dev, (size_t)kTraceJumpWords * 4u);
     grab((void**)&ws.backup, ((size_t)8u * npix + 8u) * 4u);
     grab((void**)&ws.unit_cost, (size_t)args.n_units * 4u);
     grab((void**)&ws.unit_order, (size_t)args.n_units * 4u);
@@ -2924,10 +2979,11 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
         const uint32_t want[1] = {2u * args.max_shadow_rays};
         for (int t = 0; t < 1; ++t) {
             if (ws.jump_n[t] == want[t]) continue;
-            std::vector<uint32_t> tab(kJumpWords, 0u);
+            std::vector<uint32_t> tab(kJumpWords, 0u), tab5(kJump5Words, 0u);
             if (want[t] != 0u) build_jump_table(want[t], tab.data());
-            e = hipMemcpyAsync(ws.jump_dev + (size_t)t * kJumpWords, tab.data(), kJumpWords * sizeof(uint32_t),
-                               hipMemcpyHostToDevice, stream);
+            if (CRT_JUMP5) regroup_jump_table5(tab.data(), tab5.data());
+            const std::vector<uint32_t>& up = CRT_JUMP5 ? tab5 : tab;
+            e = hipMemcpyAsync(ws.jump_dev, up.data(), (size_t)kTraceJumpWords * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream); // `tab` is pageable and about to go out of scope
             if (e != hipSuccess) return e;
             ws.jump_n[t] = want[t];
