@@ -1,7 +1,8 @@
 """Registers, scratch and LDS of the built kernels, read from the code object inside libcrt_hip.so (no GPU needed).
 
-The per-pixel trace kernel runs five waves per SIMD only while it stays under 102 registers, and five workgroups per
-CU only while a workgroup's LDS stays under 32 KB; both have been lost to innocent-looking source changes before
+The per-pixel trace kernel runs five waves per SIMD only while it needs at most 96 registers (they are handed out in
+eights: 97 means 104, and 5 x 104 exceeds the SIMD's 512), and five workgroups per CU only while a workgroup's LDS
+stays under 32 KB; both have been lost to innocent-looking source changes before
 (the compiler keeping forty table look-ups alive, a second table in LDS), at a cost of 20-30 % of the kernel's time.
 """
 import re
@@ -47,7 +48,7 @@ def test_trace_kernel_keeps_its_occupancy(tmp_path):
     coop = [v for k, v in table.items() if "wf_trace_kernelILb1" in k]
     assert len(per_pixel) == 1 and len(coop) == 1, sorted(table)
     pp, co = per_pixel[0], coop[0]
-    assert pp["vgpr_count"] <= 102, f"per-pixel trace kernel: {pp['vgpr_count']} registers, five waves per SIMD need <= 102"
+    assert pp["vgpr_count"] <= 96, f"per-pixel trace kernel: {pp['vgpr_count']} registers, five waves per SIMD need <= 96"
     assert pp["private_segment_fixed_size"] == 0, f"per-pixel trace kernel spills: {pp['private_segment_fixed_size']} bytes of scratch"
     assert pp["group_segment_fixed_size"] <= 28 * 1024, "per-pixel trace workgroup: static LDS leaves no room for five workgroups per CU"
     assert co["vgpr_count"] <= 128 and co["private_segment_fixed_size"] <= 64, co
