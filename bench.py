@@ -176,56 +176,6 @@ def config5(args, torch, crt):
     }), flush=True)
 
 
-def two_in_flight(torch, crt, ctx, st, dev, seed, frames):
-    """Throughput of a host that renders independent frames: two contexts on one GPU, each with its own stream and
-    host thread, so that one frame's trace kernel runs next to the other's filter, resolve and shade kernels.  Not the
-    headline figure (that is one frame's render time); it says what the GPU has left while a single frame runs."""
-    import threading
-    ctx2 = crt.Context(dev.index)
-    try:
-        ctx2.upload(crt.cornell_box(st.shadowSamples))
-        ctx2.rng_init(st.nx, st.ny, seed + 1)
-        ctx2.reserve_workspace(st, 0, 1)
-        fbs = [torch.empty((st.ny, st.nx, 4), dtype=torch.float32, device=dev) for _ in range(2)]
-        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-        gate = threading.Barrier(3)
-        errors = []
-
-        def run(k, c):
-            try:
-                c.render(st, fbs[k].data_ptr(), streams[k].cuda_stream)  # warm-up
-                streams[k].synchronize()
-                gate.wait()
-                for _ in range(frames):
-                    c.render(st, fbs[k].data_ptr(), streams[k].cuda_stream)
-                streams[k].synchronize()
-            except Exception as e:
-                errors.append(e)
-                gate.abort()
-                return
-            gate.wait()
-
-        threads = [threading.Thread(target=run, args=(k, c)) for k, c in enumerate((ctx, ctx2))]
-        for t in threads:
-            t.start()
-        dt = None
-        try:
-            gate.wait()
-            t0 = time.perf_counter()
-            gate.wait()
-            dt = (time.perf_counter() - t0) / (2 * frames)
-        except threading.BrokenBarrierError:
-            pass
-        for t in threads:
-            t.join()
-        if errors or dt is None:
-            raise errors[0] if errors else RuntimeError("a render thread gave up")
-        return {"ms_per_frame": dt * 1e3, "frames": 2 * frames,
-                "note": "two contexts, streams and host threads on one GPU, independent frames; throughput, not render time"}
-    finally:
-        ctx2.close()
-
-
 def launch_ranks(n):
     """Re-runs this command line as n ranks under torch.distributed.run and returns their exit status.
     The parent has made no HIP call, so the children are the only processes on the GPUs."""
@@ -393,8 +343,13 @@ def main():
     render_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # whole crt_render call, HIP events on its stream
     ktimes = {k: (ms / args.steps, n / args.steps) for k, (ms, n) in ctx.kernel_times().items() if n}
     ctx.set_timing(False)
-    # GPU time of the kernels of one render: the wavefront kernels' own events, or the single persistent kernel
-    kernel_ms = sum(ms for ms, _ in ktimes.values()) if ktimes else render_ms
+    # GPU time of the kernels of one render: the wavefront kernels' own events, or the single persistent kernel.  A
+    # large launch is rendered as two interleaved pieces side by side, each with its own five kernels per round: their
+    # times overlap and add up to more than the frame, so the frame's own events (on the caller's stream, which
+    # waits for both pieces) are the GPU time then.
+    kernel_sum = sum(ms for ms, _ in ktimes.values()) if ktimes else render_ms
+    in_pieces = bool(ktimes) and kernel_sum > 1.2 * render_ms
+    kernel_ms = render_ms if in_pieces else kernel_sum
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -453,6 +408,10 @@ def main():
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_profile": traffic_from,
                          "kernel": ("wavefront pipeline (" + "+".join(ktimes) + ")") if ktimes else "crt::render_kernel",
                          "kernel_ms": kernel_ms, "render_call_ms": render_ms,
+                         "pieces": 2 if in_pieces else 1,
+                         "pieces_note": "the launch runs as two interleaved half-frames side by side (two streams): kernel_ms is "
+                                        "the render call's HIP events on the caller's stream; the per-kernel times below are "
+                                        "summed over both pieces, which overlap, and exceed it" if in_pieces else None,
                          "kernels": {k: {"ms": ms, "launches": n} for k, (ms, n) in ktimes.items()},
                          "per_kernel": per_kernel,
                          "per_kernel_note": "model FLOPs by the kernel that does them: trace 450*shade_points + 40*gi_children, "
@@ -498,22 +457,23 @@ def main():
                     # HIP events on (which makes every frame wait for its last round, as a gl_iter 2 frame does anyway)
                     ctx.rng_init(nx, ny, args.seed, stream.cuda_stream)
                     ctx.set_timing(True)
+                    torch.cuda.synchronize(dev)
+                    t2 = time.perf_counter()
                     for _ in range(frames):
                         ctx.render(st2, fb.data_ptr(), stream.cuda_stream)
                     torch.cuda.synchronize(dev)
+                    timed_frame_ms = (time.perf_counter() - t2) / frames * 1e3
                     kt = {k: (ms / frames, n / frames) for k, (ms, n) in ctx.kernel_times().items() if n}
                     ctx.set_timing(False)
-                    kms = sum(ms for ms, _ in kt.values())
+                    ksum = sum(ms for ms, _ in kt.values())
+                    kms = timed_frame_ms if ksum > 1.2 * timed_frame_ms else ksum  # in two pieces the kernels overlap
                     ach = algorithmic_flops(w2) / (kms * 1e-3) / 1e12
                     rows[other]["roofline"] = {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                                               "frac": ach / PEAK_FP32_TFLOPS, "kernel_ms": kms, "rounds": kt["trace"][1],
+                                               "frac": ach / PEAK_FP32_TFLOPS, "kernel_ms": kms, "pieces": 2 if ksum > 1.2 * timed_frame_ms else 1,
+                                               "trace_launches": kt["trace"][1],
                                                "kernels": {k: {"ms": ms, "launches": n} for k, (ms, n) in kt.items()},
                                                "per_kernel": per_kernel_roofline(kt, w2), "work_per_frame": w2}
             out["readme_rows"] = rows
-            try:
-                out["two_frames_in_flight"] = two_in_flight(torch, crt, ctx, st, dev, args.seed, min(args.steps, 10))
-            except Exception as e:  # a side figure: never lose the line over it
-                out["two_frames_in_flight"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(gl, 20.0)
         print(json.dumps(out), flush=True)

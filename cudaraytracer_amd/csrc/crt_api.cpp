@@ -7,6 +7,7 @@
 
 #include <memory>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/crt_hip.h"
@@ -57,6 +58,15 @@ struct crt_ctx {
     hipEvent_t last_done = nullptr;
     void* last_stream = nullptr;
     bool launched = false;
+    // A large launch through the wavefront pipeline is rendered as two interleaved pieces side by side (see
+    // wants_pieces): a workspace, a stream and, while a frame runs, a host thread per piece.
+    static constexpr uint32_t kPieces = 2;
+    crt::WfWorkspace wf_piece[kPieces];
+    hipStream_t piece_stream[kPieces] = {nullptr, nullptr};
+    hipEvent_t piece_fork = nullptr, piece_join[kPieces] = {nullptr, nullptr};
+    uint32_t* frame_backup = nullptr; // 8 planes of npix words + 8: generator states, work counters, tallies at the frame's start
+    size_t frame_backup_npix = 0;
+    int piece_min_units = 8000; // launches of at least this many 64-pixel units are rendered in pieces; 0 = never (CRT_FRAME_PIECES_MIN_UNITS)
 };
 
 namespace {
@@ -80,6 +90,13 @@ int fail(crt_ctx* ctx, int code, const char* fmt, ...) {
 int bind(crt_ctx* ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return CRT_OK;
+}
+
+// Flags of frames that were left running, whichever workspace they ran in (waits for them).
+bool collect_async_all(crt_ctx* ctx) {
+    bool bad = crt::wavefront_collect_async(ctx->wf, true);
+    for (crt::WfWorkspace& w : ctx->wf_piece) bad = crt::wavefront_collect_async(w, true) || bad;
+    return bad;
 }
 
 int order_behind_last_launch(crt_ctx* ctx, hipStream_t stream) {
@@ -164,10 +181,132 @@ hipError_t reserve_workspace(crt_ctx* ctx, const crt::RenderArgs& a) {
     return e;
 }
 
+// Whether a launch is rendered as two interleaved pieces side by side, each a wavefront frame of its own (workspace,
+// stream, host thread).  The stages of one frame run one after the other, and each leaves part of the GPU idle at
+// its start and end; the trace kernel of a multi-round frame's late rounds waits more than it computes.  Two
+// half-frames fill those gaps with each other's kernels: 720x720, gl_iter 1: 18.0 against 18.7 ms; gl_iter 2: 1 071
+// against 1 204 ms (same box, one frame at a time).  Three pieces are slower than one: a third of that frame no
+// longer fills the GPU with per-pixel trace waves.  The pieces use the per-pixel trace kernel.
+bool wants_pieces(const crt_ctx* ctx, const crt::RenderArgs& a) {
+    if (ctx->piece_min_units <= 0 || a.n_units < (uint32_t)ctx->piece_min_units) return false;
+    if (ctx->pipeline == CRT_PIPELINE_PERSISTENT || a.gl_iter == 0u || a.audit != 0u || a.parts > 1u) return false;
+    if (ctx->trace_mode == CRT_TRACE_COOPERATIVE || (ctx->trace_mode == CRT_TRACE_AUTO && ctx->coop_permille >= 0)) return false;
+    if (ctx->wf.max_rounds != 0u) return false; // the round limit times one pipeline's rounds
+    return true;
+}
+
+crt::RenderArgs piece_args(const crt::RenderArgs& a, uint32_t k) {
+    crt::RenderArgs p = a;
+    p.parts = crt_ctx::kPieces;
+    p.part = k;
+    p.n_units = (a.n_units + crt_ctx::kPieces - 1u - k) / crt_ctx::kPieces;
+    p.cooperative = 0u;
+    return p;
+}
+
+// Streams, events and workspaces of the pieces; false when one of them cannot be had (the launch then runs whole).
+bool reserve_pieces(crt_ctx* ctx, const crt::RenderArgs& a) {
+    for (uint32_t k = 0; k < crt_ctx::kPieces; ++k) {
+        if (!ctx->piece_stream[k] && hipStreamCreateWithFlags(&ctx->piece_stream[k], hipStreamNonBlocking) != hipSuccess) return false;
+        if (!ctx->piece_join[k] && hipEventCreateWithFlags(&ctx->piece_join[k], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    if (!ctx->piece_fork && hipEventCreateWithFlags(&ctx->piece_fork, hipEventDisableTiming) != hipSuccess) return false;
+    const size_t npix = (size_t)a.nx * a.ny;
+    if (ctx->frame_backup_npix != npix) {
+        (void)hipFree(ctx->frame_backup);
+        ctx->frame_backup = nullptr;
+        ctx->frame_backup_npix = 0;
+        if (hipMalloc((void**)&ctx->frame_backup, (8u * npix + 8u) * sizeof(uint32_t)) != hipSuccess) return false;
+        ctx->frame_backup_npix = npix;
+    }
+    for (uint32_t k = 0; k < crt_ctx::kPieces; ++k) {
+        const crt::RenderArgs p = piece_args(a, k);
+        if (!crt::wavefront_supports(p)) return false;
+        hipError_t e = hipSuccess;
+        for (size_t budget = ctx->workspace_limit / crt_ctx::kPieces;; budget /= 2) {
+            e = crt::wavefront_reserve(ctx->wf_piece[k], p, ctx->scene_host.n_lights, budget);
+            if (e != hipErrorOutOfMemory || budget < ((size_t)1 << 30)) break;
+            (void)hipGetLastError();
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    return true;
+}
+
+void release_pieces(crt_ctx* ctx) {
+    for (uint32_t k = 0; k < crt_ctx::kPieces; ++k) crt::wavefront_release(ctx->wf_piece[k]);
+}
+
+// Copies generator states, work counters and tallies to (save) or from the frame backup, on `stream`.
+hipError_t frame_backup_copy(crt_ctx* ctx, const crt::RenderArgs& a, bool save, hipStream_t stream) {
+    const size_t npix = (size_t)a.nx * a.ny;
+    uint32_t* b = ctx->frame_backup;
+    auto copy = [&](void* live, uint32_t* saved, size_t bytes) {
+        return save ? hipMemcpyAsync(saved, live, bytes, hipMemcpyDeviceToDevice, stream)
+                    : hipMemcpyAsync(live, saved, bytes, hipMemcpyDeviceToDevice, stream);
+    };
+    hipError_t e = copy(a.rng, b, npix * 6u * sizeof(uint32_t));
+    if (e == hipSuccess) e = copy(a.counters, b + 6u * npix, npix * 2u * sizeof(uint32_t));
+    if (e == hipSuccess) e = copy(a.wave_tallies, b + 8u * npix, 8u * sizeof(uint32_t));
+    return e;
+}
+
+struct PieceResult {
+    hipError_t err = hipSuccess;
+    bool overflow = false, truncated = false, needs_redo = false;
+};
+
+// The launch as two pieces side by side.  *done is false when a piece's ray queue overflowed: everything is back
+// where the frame started and the caller renders the launch whole (that path saves and redoes by itself).
+int run_pieces(crt_ctx* ctx, const crt::RenderArgs& a, hipStream_t stream, bool* done) {
+    *done = false;
+    HIP_TRY(ctx, frame_backup_copy(ctx, a, true, stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->piece_fork, stream));
+    PieceResult res[crt_ctx::kPieces];
+    auto run = [&](uint32_t k) {
+        PieceResult& r = res[k];
+        r.err = hipSetDevice(ctx->device);
+        if (r.err == hipSuccess) r.err = hipStreamWaitEvent(ctx->piece_stream[k], ctx->piece_fork, 0);
+        if (r.err == hipSuccess)
+            r.err = crt::launch_wavefront(piece_args(a, k), ctx->wf_piece[k], ctx->piece_stream[k], &r.overflow, &r.truncated, true,
+                                          &r.needs_redo);
+        const hipError_t e2 = hipEventRecord(ctx->piece_join[k], ctx->piece_stream[k]); // also after a failure: part may be queued
+        if (r.err == hipSuccess) r.err = e2;
+    };
+    {
+        std::thread other(run, 1u);
+        run(0u);
+        other.join();
+    }
+    for (uint32_t k = 0; k < crt_ctx::kPieces; ++k) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->piece_join[k], 0));
+    bool overflow = false, redo = false;
+    for (const PieceResult& r : res) {
+        if (r.err != hipSuccess) return fail(ctx, CRT_ERR_HIP, "wavefront pipeline (piece of a frame): %s", hipGetErrorString(r.err));
+        overflow = overflow || r.overflow;
+        redo = redo || r.needs_redo;
+    }
+    if (overflow) return fail(ctx, CRT_ERR_HIP, "wavefront pipeline: a device queue overflowed (in this frame or one left running before it)");
+    if (redo) {
+        HIP_TRY(ctx, frame_backup_copy(ctx, a, false, stream));
+        return CRT_OK;
+    }
+    *done = true;
+    return CRT_OK;
+}
+
 // Runs one launch through the pipeline the context selects.
 int run_pipeline(crt_ctx* ctx, const crt::RenderArgs& args, hipStream_t stream) {
     crt::RenderArgs a = args;
     a.cooperative = pick_cooperative(ctx, a);
+    if (wants_pieces(ctx, a) && reserve_pieces(ctx, a)) {
+        bool done = false;
+        const int rc = run_pieces(ctx, a, stream, &done);
+        if (rc != CRT_OK || done) return rc;
+        release_pieces(ctx); // make room: the launch is rendered whole below, which needs the workspace limit once more
+    }
     const bool can_wf = crt::wavefront_supports(a);
     if (ctx->pipeline == CRT_PIPELINE_WAVEFRONT && !can_wf)
         return fail(ctx, CRT_ERR_UNSUPPORTED, "the wavefront pipeline does not implement these settings");
@@ -215,6 +354,7 @@ int crt_create(crt_ctx** out, int device) {
     if (!ctx) return CRT_ERR_INVALID;
     ctx->device = device;
     if (const char* env = getenv("CRT_COOP_PERMILLE")) ctx->coop_permille = atoi(env) < 0 ? 0 : atoi(env);
+    if (const char* env = getenv("CRT_FRAME_PIECES_MIN_UNITS")) ctx->piece_min_units = atoi(env); // a measuring and testing aid
     const size_t ltc_bytes = (size_t)(crt_ltc_tables_blob_end - crt_ltc_tables_blob);
     if (ltc_bytes != 2u * 64u * 64u * 4u * sizeof(float) || hipSetDevice(device) != hipSuccess ||
         hipMalloc((void**)&ctx->ltc_dev, ltc_bytes) != hipSuccess ||
@@ -266,6 +406,13 @@ void crt_destroy(crt_ctx* ctx) {
         (void)hipFree(ctx->unit_counter);
         if (ctx->last_done) (void)hipEventDestroy(ctx->last_done);
         crt::wavefront_release(ctx->wf);
+        release_pieces(ctx);
+        for (uint32_t k = 0; k < crt_ctx::kPieces; ++k) {
+            if (ctx->piece_stream[k]) (void)hipStreamDestroy(ctx->piece_stream[k]);
+            if (ctx->piece_join[k]) (void)hipEventDestroy(ctx->piece_join[k]);
+        }
+        if (ctx->piece_fork) (void)hipEventDestroy(ctx->piece_fork);
+        (void)hipFree(ctx->frame_backup);
     }
     delete ctx;
 }
@@ -285,6 +432,7 @@ int crt_scene_upload(crt_ctx* ctx, const crt_scene_desc* scene) {
     HIP_TRY(ctx, hipDeviceSynchronize()); // no render may still be reading the old scene
     ctx->has_scene = false;               // until the device holds the new one
     ctx->wf.order_valid = false;          // the trace kernel's launch order was estimated on the old scene
+    for (crt::WfWorkspace& w : ctx->wf_piece) w.order_valid = false;
     HIP_TRY(ctx, hipMemcpy(ctx->scene_dev, flat.get(), sizeof(crt::DevScene), hipMemcpyHostToDevice));
     ctx->scene_host = *flat;
     ctx->has_scene = true;
@@ -330,7 +478,7 @@ int crt_rng_export(crt_ctx* ctx, uint32_t* host_state6) {
     const size_t npix = (size_t)ctx->rng_nx * ctx->rng_ny;
     std::vector<uint32_t> planes(npix * 6);
     HIP_TRY(ctx, hipDeviceSynchronize());
-    if (crt::wavefront_collect_async(ctx->wf, true))
+    if (collect_async_all(ctx))
         return fail(ctx, CRT_ERR_HIP, "wavefront pipeline: a device queue overflowed in an earlier frame");
     HIP_TRY(ctx, hipMemcpy(planes.data(), ctx->rng_dev, npix * 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (size_t p = 0; p < npix; ++p)
@@ -467,7 +615,7 @@ int crt_stats_since_init(crt_ctx* ctx, const crt_settings* st, crt_stats* out) {
     const size_t npix = (size_t)ctx->rng_nx * ctx->rng_ny;
     std::vector<uint32_t> d_now(npix), d_init(npix), cnt(npix * 2);
     HIP_TRY(ctx, hipDeviceSynchronize());
-    if (crt::wavefront_collect_async(ctx->wf, true))
+    if (collect_async_all(ctx))
         return fail(ctx, CRT_ERR_HIP, "wavefront pipeline: a device queue overflowed in an earlier frame");
     HIP_TRY(ctx, hipMemcpy(d_now.data(), ctx->rng_dev + 5 * npix, npix * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(d_init.data(), ctx->rng_init_d, npix * 4, hipMemcpyDeviceToHost));
@@ -499,10 +647,13 @@ int crt_set_pipeline(crt_ctx* ctx, int pipeline) {
 
 int crt_set_timing(crt_ctx* ctx, int enabled) {
     if (!ctx) return CRT_ERR_INVALID;
-    ctx->wf.timing = enabled != 0;
-    for (uint32_t k = 0; k < crt::WF_KERNEL_COUNT; ++k) {
-        ctx->wf.kernel_ms[k] = 0.0;
-        ctx->wf.kernel_launches[k] = 0;
+    crt::WfWorkspace* all[] = {&ctx->wf, &ctx->wf_piece[0], &ctx->wf_piece[1]};
+    for (crt::WfWorkspace* w : all) {
+        w->timing = enabled != 0;
+        for (uint32_t k = 0; k < crt::WF_KERNEL_COUNT; ++k) {
+            w->kernel_ms[k] = 0.0;
+            w->kernel_launches[k] = 0;
+        }
     }
     return CRT_OK;
 }
@@ -510,9 +661,10 @@ int crt_set_timing(crt_ctx* ctx, int enabled) {
 int crt_get_kernel_times(crt_ctx* ctx, double ms[5], uint64_t launches[5]) {
     if (!ctx) return CRT_ERR_INVALID;
     if (!ms || !launches) return fail(ctx, CRT_ERR_INVALID, "NULL argument");
+    // a launch rendered in two pieces has run every kernel twice, side by side: the times add up to more than the frame's
     for (uint32_t k = 0; k < 5u; ++k) {
-        ms[k] = ctx->wf.kernel_ms[k];
-        launches[k] = ctx->wf.kernel_launches[k];
+        ms[k] = ctx->wf.kernel_ms[k] + ctx->wf_piece[0].kernel_ms[k] + ctx->wf_piece[1].kernel_ms[k];
+        launches[k] = ctx->wf.kernel_launches[k] + ctx->wf_piece[0].kernel_launches[k] + ctx->wf_piece[1].kernel_launches[k];
     }
     return CRT_OK;
 }
@@ -557,6 +709,7 @@ int crt_reserve_workspace(crt_ctx* ctx, const crt_settings* st, uint32_t rank, u
     a.world = world;
     a.n_units = world == 1 ? a.tiles_x * a.tiles_y : crt_shard_tiles(st->nx, st->ny, rank, world);
     a.cooperative = pick_cooperative(ctx, a); // before the check: the cooperative kernel needs more record slack
+    if (wants_pieces(ctx, a) && reserve_pieces(ctx, a)) return CRT_OK; // crt_render takes the launch in two pieces
     if (!crt::wavefront_supports(a)) return CRT_OK; // crt_render takes the persistent kernel (or refuses, if told to use the pipeline)
     const hipError_t reserved = reserve_workspace(ctx, a);
     if (reserved != hipSuccess) {

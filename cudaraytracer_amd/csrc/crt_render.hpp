@@ -34,6 +34,8 @@ struct RenderArgs {
     uint32_t horizon_clip;    // some light takes the horizon-clipping LTC branch (crt_light::horizonClip)
     uint32_t cooperative;     // wavefront pipeline: per mille of the work units (most expensive first) whose last GI
                               // level the trace kernel expands with one lane per child ray; 0 = none, 1000 = all
+    uint32_t part, parts;     // parts > 1: this launch is one of `parts` interleaved pieces of a larger one; its unit u
+                              // is unit u * parts + part of that launch (n_units counts this piece's units)
 };
 
 // ---- wavefront pipeline (crt_wavefront.hip)
@@ -121,7 +123,10 @@ void wavefront_release(WfWorkspace& ws);
 // ray queue overflowed is rendered again from the saved generator states with launches sized for the worst
 // case.  *overflow is set when a capacity check on the device failed for good.
 // *truncated is set when the round limit (WfWorkspace::max_rounds) ended the frame with pixels unfinished.
-hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow, bool* truncated);
+// no_redo: the caller takes care of a frame whose ray queue overflowed (it renders pieces of a frame side by side and
+// has to start all of them again): nothing is saved beforehand, and *needs_redo is set instead of rendering again.
+hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow, bool* truncated,
+                            bool no_redo = false, bool* needs_redo = nullptr);
 // Looks at the counter copies of frames that were left running: with `wait` the call waits for them, without
 // it takes those that have landed.  Returns true (once) if one of them had raised a device flag.
 bool wavefront_collect_async(WfWorkspace& ws, bool wait);

@@ -18,6 +18,7 @@ DI PixelMap map_pixel(const RenderArgs& a, uint32_t unit, uint32_t idx) {
     m.valid = false;
     m.i = m.j = 0;
     m.out_index = 0;
+    if (a.parts > 1u) unit = unit * a.parts + a.part; // a piece of a larger launch: that launch's unit
     if (a.mode == MODE_FULL || a.mode == MODE_SHARD) {
         uint32_t tile = (a.mode == MODE_SHARD) ? unit * a.world + a.rank : unit;
         uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;

@@ -2878,9 +2878,11 @@ hipError_t run_frame(const RenderArgs& args, WfWorkspace& ws, WfArgs& w, const G
 
 } // namespace
 
-hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow, bool* truncated) {
+hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t stream, bool* overflow, bool* truncated,
+                            bool no_redo, bool* needs_redo) {
     *overflow = false;
     *truncated = false;
+    if (needs_redo) *needs_redo = false;
     if (args.n_units == 0) return hipSuccess;
     if (ws.timing && !ws.timer) ws.timer = new EventTimer();
     EventTimer* timer = ws.timing ? static_cast<EventTimer*>(ws.timer) : nullptr;
@@ -3053,7 +3055,7 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     const uint64_t rays_per_record = args.max_shadow_rays ? args.max_shadow_rays : 1u;
     const bool can_overflow = (uint64_t)cap_used * rays_per_record + (uint64_t)g.filter * w.qchunk > ws.qcap;
     const size_t npix = ws.npix;
-    if (can_overflow) {
+    if (can_overflow && !no_redo) {
         // what a second rendering of this frame starts from: generator states, work counters, tallies
         e = hipMemcpyAsync(ws.backup, args.rng, npix * 6u * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
         if (e == hipSuccess)
@@ -3069,6 +3071,11 @@ hipError_t launch_wavefront(const RenderArgs& args, WfWorkspace& ws, hipStream_t
     e = run_frame(args, ws, w, g, n_coop, false, leave_running, stream, timer, flags);
     if (e != hipSuccess) return e;
     if (!leave_running && ws.max_rounds != 0u && ws.ctrs_host[WF_CTR_ACTIVE] != 0u) *truncated = true;
+    if (flags[0] == 0u && flags[1] != 0u && can_overflow && no_redo) {
+        if (needs_redo) *needs_redo = true; // the caller starts the frame again (its other pieces too)
+        if (timer) timer->collect(ws);
+        return hipSuccess;
+    }
     if (flags[0] == 0u && flags[1] != 0u && can_overflow) {
         // rays were dropped: the same frame again from where it started, with launches that cannot overflow
         e = hipMemcpyAsync(args.rng, ws.backup, npix * 6u * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);

@@ -422,12 +422,17 @@ def test_filter_decisions_agree_with_the_exact_test(kind):
 
 
 @pytest.mark.gpu
-def test_wavefront_redoes_a_round_when_the_ray_queue_overflows(oracle):
+@pytest.mark.parametrize("pieces,n", [(False, 64), (True, 96)])
+def test_wavefront_redoes_a_round_when_the_ray_queue_overflows(oracle, monkeypatch, pieces, n):
     """A glass sphere under the light leaves nearly every shadow ray undecided.  With a 1 MiB workspace
     limit the undecided-ray queue holds 2^20 rays, the first rendering overflows it (the device drops rays and
     raises a flag) and the frame is rendered again from the saved generator states with batched launches that
-    cannot overflow; image and end states must not change."""
+    cannot overflow; image and end states must not change.  With `pieces` the frame starts as two pieces side by
+    side (each with a queue of its own, hence the larger image); a piece that overflows sends the whole launch back
+    to where it started, and it is rendered in one piece, which redoes as above."""
     from cudaraytracer_amd import abi
+    if pieces:
+        monkeypatch.setenv("CRT_FRAME_PIECES_MIN_UNITS", "2")  # read by crt_create
 
     def scene(mod):
         base = crt.cornell_box(50)
@@ -438,7 +443,7 @@ def test_wavefront_redoes_a_round_when_the_ray_queue_overflows(oracle):
         cam = abi.crt_camera.from_buffer_copy(bytes(base.camera))
         return mod.Scene(cam, geo, lights)
 
-    st = crt.make_settings(nx=64, ny=64, aa_iter=1, gl_iter=1, ind_rays=12, shadowSamples=50)
+    st = crt.make_settings(nx=n, ny=n, aa_iter=1, gl_iter=1, ind_rays=12, shadowSamples=50)
     ctx = _wavefront_ctx()
     try:
         ctx.set_workspace_limit(1 << 20)

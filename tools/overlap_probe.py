@@ -1,8 +1,10 @@
 """Would a frame get faster if its kernels overlapped?
-    python tools/overlap_probe.py PARTS [WORLD] [gl_iter] [steps] [trace mode] [stagger ms]
+    python tools/overlap_probe.py PARTS [WORLD] [gl_iter] [steps] [trace mode] [stagger ms] [lockstep 0|1]
 PARTS contexts, each with its own stream and host thread, render shard (r % WORLD) of WORLD of the 720x720 Cornell box
 on ONE GPU at the same time, thread r starting r * stagger ms late, so that one launch's trace kernel runs next to
 another's filter, resolve and shade kernels.  WORLD = PARTS: one frame in pieces; WORLD = 1: whole frames side by side.
+With lockstep the threads wait for each other after every frame (and every stream is drained), so that the figure is
+one frame's time, not the throughput of frames that run into each other.
 Prints the wall time per whole frame next to the plain single-launch frame."""
 import sys
 import threading
@@ -20,6 +22,7 @@ gl = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 mode = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 stagger = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
+lockstep = len(sys.argv) > 7 and sys.argv[7] == "1"
 st = crt.make_settings(gl_iter=gl)
 scene = crt.cornell_box(50)
 dev = torch.device("cuda", 0)
@@ -38,6 +41,7 @@ def frame_ms(parts, world, stagger):
         ctxs.append(c)
         streams.append(torch.cuda.Stream(dev))
     gate = threading.Barrier(parts + 1)
+    frame_gate = threading.Barrier(parts)
 
     def run(r):
         s = streams[r].cuda_stream
@@ -48,6 +52,9 @@ def frame_ms(parts, world, stagger):
             time.sleep(r * stagger * 1e-3)
         for _ in range(steps):
             ctxs[r].render_shard(st, r % world, world, bufs[r], s)
+            if lockstep:
+                streams[r].synchronize()
+                frame_gate.wait()
         streams[r].synchronize()
         gate.wait()
 
