@@ -17,6 +17,9 @@
  * counters, so the library runs them one after the other: a call on another
  * stream than the context's previous launch is queued behind that launch (an
  * event per context).  Buffers the caller owns are the caller's to order.
+ * A large launch (8 000 units of 64 pixels or more) is rendered as two pieces
+ * side by side on two streams of the context, by two host threads for the
+ * duration of the call; the caller's stream waits for both.
  *
  * Memory: "dev" pointers are device (HBM) addresses owned by the caller;
  * "host" pointers are ordinary host memory.  The context owns the flattened
@@ -274,7 +277,8 @@ int crt_set_trace_mode(crt_ctx* ctx, int mode);
 /* Per-kernel GPU time of the wavefront pipeline, measured with HIP events on the launch stream.
  * crt_set_timing(ctx, 1) starts (and zeroes) the accumulation, crt_get_kernel_times returns
  * milliseconds and launch counts in the order trace, filter, resolve, shade, sum.  A workspace
- * reallocation (new image size) keeps the setting but restarts the totals.  Measurement only; the
+ * reallocation (new image size) keeps the setting but restarts the totals.  For a launch rendered in two
+ * pieces the figures are sums over both pieces, whose kernels overlap.  Measurement only; the
  * reference prints one wall-clock "Render time" (main.cu:712-716). */
 int crt_set_timing(crt_ctx* ctx, int enabled);
 int crt_get_kernel_times(crt_ctx* ctx, double ms[5], uint64_t launches[5]);
