@@ -66,7 +66,7 @@ struct crt_ctx {
     hipEvent_t piece_fork = nullptr, piece_join[kPieces] = {nullptr, nullptr};
     uint32_t* frame_backup = nullptr; // 8 planes of npix words + 8: generator states, work counters, tallies at the frame's start
     size_t frame_backup_npix = 0;
-    int piece_min_units = 8000; // launches of at least this many 64-pixel units are rendered in pieces; 0 = never (CRT_FRAME_PIECES_MIN_UNITS)
+    int piece_min_units = 1000; // launches of at least this many 64-pixel units are rendered in pieces; 0 = never (CRT_FRAME_PIECES_MIN_UNITS)
 };
 
 namespace {
@@ -184,15 +184,15 @@ hipError_t reserve_workspace(crt_ctx* ctx, const crt::RenderArgs& a) {
 // Whether a launch is rendered as two interleaved pieces side by side, each a wavefront frame of its own (workspace,
 // stream, host thread).  The stages of one frame run one after the other, and each leaves part of the GPU idle at
 // its start and end; the trace kernel of a multi-round frame's late rounds waits more than it computes.  Two
-// half-frames fill those gaps with each other's kernels: 720x720, gl_iter 1: 18.0 against 18.7 ms; gl_iter 2: 1 071
-// against 1 204 ms (same box, one frame at a time).  Three pieces are slower than one: a third of that frame no
-// longer fills the GPU with per-pixel trace waves.  The pieces use the per-pixel trace kernel.
+// half-frames fill those gaps with each other's kernels: 720x720, gl_iter 1: 17.9 against 18.6 ms; gl_iter 2: 1 070
+// against 1 200 ms; an eighth of that frame (a rank of an 8-GPU job, 1 013 units): 3.00 against 3.04 ms and 178
+// against 191 ms; a sixteenth: 2.04 against 1.90 ms, hence the threshold.  Three pieces of the whole frame are slower
+// than one launch.  The pieces run the trace kernels that the whole launch's size picks (pick_cooperative): halves
+// of the whole frame with the per-pixel kernel alone, 1 074 ms at gl_iter 2, with the mix a half-frame would pick
+// for itself, 1 158.
 bool wants_pieces(const crt_ctx* ctx, const crt::RenderArgs& a) {
     if (ctx->piece_min_units <= 0 || a.n_units < (uint32_t)ctx->piece_min_units) return false;
-    if (ctx->pipeline == CRT_PIPELINE_PERSISTENT || a.gl_iter == 0u || a.audit != 0u || a.parts > 1u) return false;
-    if (ctx->trace_mode == CRT_TRACE_COOPERATIVE || (ctx->trace_mode == CRT_TRACE_AUTO && ctx->coop_permille >= 0)) return false;
-    if (ctx->wf.max_rounds != 0u) return false; // the round limit times one pipeline's rounds
-    return true;
+    return ctx->pipeline != CRT_PIPELINE_PERSISTENT && a.gl_iter != 0u && a.audit == 0u && a.parts <= 1u;
 }
 
 crt::RenderArgs piece_args(const crt::RenderArgs& a, uint32_t k) {
@@ -200,8 +200,7 @@ crt::RenderArgs piece_args(const crt::RenderArgs& a, uint32_t k) {
     p.parts = crt_ctx::kPieces;
     p.part = k;
     p.n_units = (a.n_units + crt_ctx::kPieces - 1u - k) / crt_ctx::kPieces;
-    p.cooperative = 0u;
-    return p;
+    return p; // `cooperative` stays what the whole launch's size picked
 }
 
 // Streams, events and workspaces of the pieces; false when one of them cannot be had (the launch then runs whole).
@@ -282,11 +281,12 @@ int run_pieces(crt_ctx* ctx, const crt::RenderArgs& a, hipStream_t stream, bool*
         other.join();
     }
     for (uint32_t k = 0; k < crt_ctx::kPieces; ++k) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->piece_join[k], 0));
-    bool overflow = false, redo = false;
+    bool overflow = false, redo = false, truncated = false;
     for (const PieceResult& r : res) {
         if (r.err != hipSuccess) return fail(ctx, CRT_ERR_HIP, "wavefront pipeline (piece of a frame): %s", hipGetErrorString(r.err));
         overflow = overflow || r.overflow;
         redo = redo || r.needs_redo;
+        truncated = truncated || r.truncated;
     }
     if (overflow) return fail(ctx, CRT_ERR_HIP, "wavefront pipeline: a device queue overflowed (in this frame or one left running before it)");
     if (redo) {
@@ -294,6 +294,9 @@ int run_pieces(crt_ctx* ctx, const crt::RenderArgs& a, hipStream_t stream, bool*
         return CRT_OK;
     }
     *done = true;
+    if (truncated)
+        return fail(ctx, CRT_ERR_TRUNCATED, "frame stopped after %u rounds (crt_set_round_limit): image unfinished, RNG states mid-tree",
+                    ctx->wf.max_rounds);
     return CRT_OK;
 }
 
@@ -724,6 +727,7 @@ int crt_reserve_workspace(crt_ctx* ctx, const crt_settings* st, uint32_t rank, u
 int crt_set_round_limit(crt_ctx* ctx, uint32_t rounds) {
     if (!ctx) return CRT_ERR_INVALID;
     ctx->wf.max_rounds = rounds;
+    for (crt::WfWorkspace& w : ctx->wf_piece) w.max_rounds = rounds; // each piece of a launch stops after that many rounds of its own
     return CRT_OK;
 }
 
