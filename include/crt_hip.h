@@ -17,7 +17,7 @@
  * counters, so the library runs them one after the other: a call on another
  * stream than the context's previous launch is queued behind that launch (an
  * event per context).  Buffers the caller owns are the caller's to order.
- * A large launch (8 000 units of 64 pixels or more) is rendered as two pieces
+ * A large launch (1 000 units of 64 pixels or more) is rendered as two pieces
  * side by side on two streams of the context, by two host threads for the
  * duration of the call; the caller's stream waits for both.
  *
