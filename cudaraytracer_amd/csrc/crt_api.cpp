@@ -5,7 +5,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -32,6 +35,55 @@ static uint32_t* g_scratch_ptr[64] = {nullptr}; // per device: device address of
 static hipEvent_t g_static_done[64] = {nullptr};
 static void* g_static_stream[64] = {nullptr};
 static bool g_static_used[64] = {false};
+
+// The context's second host thread: it runs the second piece of a launch that is rendered in two pieces, and sleeps
+// between frames (starting a thread per frame costs a few per cent of a 3 ms frame).
+class PieceWorker {
+public:
+    PieceWorker() : th_([this] { loop(); }) {}
+    ~PieceWorker() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void submit(std::function<void()> job) {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = std::move(job);
+            pending_ = true;
+            done_ = false;
+        }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return done_; });
+    }
+
+private:
+    void loop() {
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [this] { return pending_ || quit_; });
+            if (quit_) return;
+            std::function<void()> job = std::move(job_);
+            pending_ = false;
+            g.unlock();
+            job();
+            g.lock();
+            done_ = true;
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool pending_ = false, done_ = true, quit_ = false;
+    std::thread th_; // last: the thread starts in the constructor and uses the members above
+};
 
 struct crt_ctx {
     int device = 0;
@@ -64,6 +116,7 @@ struct crt_ctx {
     crt::WfWorkspace wf_piece[kPieces];
     hipStream_t piece_stream[kPieces] = {nullptr, nullptr};
     hipEvent_t piece_fork = nullptr, piece_join[kPieces] = {nullptr, nullptr};
+    std::unique_ptr<PieceWorker> piece_worker; // started with the first launch that runs in pieces
     uint32_t* frame_backup = nullptr; // 8 planes of npix words + 8: generator states, work counters, tallies at the frame's start
     size_t frame_backup_npix = 0;
     int piece_min_units = 1000; // launches of at least this many 64-pixel units are rendered in pieces; 0 = never (CRT_FRAME_PIECES_MIN_UNITS)
@@ -210,6 +263,13 @@ bool reserve_pieces(crt_ctx* ctx, const crt::RenderArgs& a) {
         if (!ctx->piece_join[k] && hipEventCreateWithFlags(&ctx->piece_join[k], hipEventDisableTiming) != hipSuccess) return false;
     }
     if (!ctx->piece_fork && hipEventCreateWithFlags(&ctx->piece_fork, hipEventDisableTiming) != hipSuccess) return false;
+    if (!ctx->piece_worker) {
+        try {
+            ctx->piece_worker.reset(new PieceWorker());
+        } catch (...) { // no memory, or no thread to be had: the launch runs whole
+            return false;
+        }
+    }
     const size_t npix = (size_t)a.nx * a.ny;
     if (ctx->frame_backup_npix != npix) {
         (void)hipFree(ctx->frame_backup);
@@ -275,11 +335,9 @@ int run_pieces(crt_ctx* ctx, const crt::RenderArgs& a, hipStream_t stream, bool*
         const hipError_t e2 = hipEventRecord(ctx->piece_join[k], ctx->piece_stream[k]); // also after a failure: part may be queued
         if (r.err == hipSuccess) r.err = e2;
     };
-    {
-        std::thread other(run, 1u);
-        run(0u);
-        other.join();
-    }
+    ctx->piece_worker->submit([&run] { run(1u); });
+    run(0u);
+    ctx->piece_worker->wait();
     for (uint32_t k = 0; k < crt_ctx::kPieces; ++k) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->piece_join[k], 0));
     bool overflow = false, redo = false, truncated = false;
     for (const PieceResult& r : res) {
