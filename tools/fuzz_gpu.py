@@ -1,4 +1,7 @@
-"""Long form of the random-scene parity test: python tools/fuzz_gpu.py FIRST COUNT [wild|wide] (needs a GPU)."""
+"""Long form of the random-scene parity test: python tools/fuzz_gpu.py FIRST COUNT [wild|wide] [pieces] (needs a GPU).
+With `pieces` every launch of two work units or more is rendered as two pieces side by side (the library does that
+from 1 000 units on) and the audit, which such launches do not run in pieces, stays off."""
+import os
 import sys
 from pathlib import Path
 
@@ -14,6 +17,9 @@ from scene_fuzz import random_scene  # noqa: E402
 first, count = int(sys.argv[1]), int(sys.argv[2])
 wild = len(sys.argv) > 3 and sys.argv[3] in ("wild", "wide")
 wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+pieces = "pieces" in sys.argv[3:]
+if pieces:
+    os.environ["CRT_FRAME_PIECES_MIN_UNITS"] = "2"  # read by crt_create
 failures = 0
 for seed in range(first, first + count):
     S = 3 + seed % 7
@@ -30,7 +36,7 @@ for seed in range(first, first + count):
     scene = random_scene(crt, seed, S, wild)
     ctx = crt.Context(0)
     ctx.set_pipeline(abi.CRT_PIPELINE_PERSISTENT if seed % 8 == 5 else abi.CRT_PIPELINE_WAVEFRONT)
-    ctx.set_audit(True)
+    ctx.set_audit(not pieces)
     ctx.set_trace_mode(abi.CRT_TRACE_COOPERATIVE if seed % 2 == 0 else abi.CRT_TRACE_PER_PIXEL)
     if seed % 7 == 3:
         ctx.set_workspace_limit(1 << 20)
