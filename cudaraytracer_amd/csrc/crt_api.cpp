@@ -119,6 +119,8 @@ struct crt_ctx {
     std::unique_ptr<PieceWorker> piece_worker; // started with the first launch that runs in pieces
     uint32_t* frame_backup = nullptr; // 8 planes of npix words + 8: generator states, work counters, tallies at the frame's start
     size_t frame_backup_npix = 0;
+    bool piece_overflowed = false;       // the pieces of launch `piece_overflow_key` overflowed their ray queues
+    crt::RenderArgs piece_overflow_key{};
     int piece_min_units = 1000; // launches of at least this many 64-pixel units are rendered in pieces; 0 = never (CRT_FRAME_PIECES_MIN_UNITS)
 };
 
@@ -256,6 +258,19 @@ crt::RenderArgs piece_args(const crt::RenderArgs& a, uint32_t k) {
     return p; // `cooperative` stays what the whole launch's size picked
 }
 
+void release_pieces(crt_ctx* ctx) {
+    for (uint32_t k = 0; k < crt_ctx::kPieces; ++k) crt::wavefront_release(ctx->wf_piece[k]);
+}
+
+// A launch whose pieces overflowed their ray queues is rendered whole from then on (until the scene changes): it
+// would only overflow again.
+bool same_launch(const crt::RenderArgs& a, const crt::RenderArgs& b) {
+    return a.n_units == b.n_units && a.nx == b.nx && a.ny == b.ny && a.aa_iter == b.aa_iter && a.ref_iter == b.ref_iter &&
+           a.gl_iter == b.gl_iter && a.ind_rays == b.ind_rays && a.mode == b.mode && a.rank == b.rank && a.world == b.world &&
+           a.tx == b.tx && a.ty == b.ty && a.win_bx == b.win_bx && a.win_by == b.win_by && a.start_bx == b.start_bx &&
+           a.start_by == b.start_by;
+}
+
 // Streams, events and workspaces of the pieces; false when one of them cannot be had (the launch then runs whole).
 bool reserve_pieces(crt_ctx* ctx, const crt::RenderArgs& a) {
     for (uint32_t k = 0; k < crt_ctx::kPieces; ++k) {
@@ -289,14 +304,11 @@ bool reserve_pieces(crt_ctx* ctx, const crt::RenderArgs& a) {
         }
         if (e != hipSuccess) {
             (void)hipGetLastError();
+            release_pieces(ctx); // the launch runs whole and wants the memory
             return false;
         }
     }
     return true;
-}
-
-void release_pieces(crt_ctx* ctx) {
-    for (uint32_t k = 0; k < crt_ctx::kPieces; ++k) crt::wavefront_release(ctx->wf_piece[k]);
 }
 
 // Copies generator states, work counters and tallies to (save) or from the frame backup, on `stream`.
@@ -362,11 +374,13 @@ int run_pieces(crt_ctx* ctx, const crt::RenderArgs& a, hipStream_t stream, bool*
 int run_pipeline(crt_ctx* ctx, const crt::RenderArgs& args, hipStream_t stream) {
     crt::RenderArgs a = args;
     a.cooperative = pick_cooperative(ctx, a);
-    if (wants_pieces(ctx, a) && reserve_pieces(ctx, a)) {
+    if (wants_pieces(ctx, a) && !(ctx->piece_overflowed && same_launch(a, ctx->piece_overflow_key)) && reserve_pieces(ctx, a)) {
         bool done = false;
         const int rc = run_pieces(ctx, a, stream, &done);
         if (rc != CRT_OK || done) return rc;
         release_pieces(ctx); // make room: the launch is rendered whole below, which needs the workspace limit once more
+        ctx->piece_overflowed = true;
+        ctx->piece_overflow_key = a;
     }
     const bool can_wf = crt::wavefront_supports(a);
     if (ctx->pipeline == CRT_PIPELINE_WAVEFRONT && !can_wf)
@@ -494,6 +508,7 @@ int crt_scene_upload(crt_ctx* ctx, const crt_scene_desc* scene) {
     ctx->has_scene = false;               // until the device holds the new one
     ctx->wf.order_valid = false;          // the trace kernel's launch order was estimated on the old scene
     for (crt::WfWorkspace& w : ctx->wf_piece) w.order_valid = false;
+    ctx->piece_overflowed = false;
     HIP_TRY(ctx, hipMemcpy(ctx->scene_dev, flat.get(), sizeof(crt::DevScene), hipMemcpyHostToDevice));
     ctx->scene_host = *flat;
     ctx->has_scene = true;
@@ -770,7 +785,8 @@ int crt_reserve_workspace(crt_ctx* ctx, const crt_settings* st, uint32_t rank, u
     a.world = world;
     a.n_units = world == 1 ? a.tiles_x * a.tiles_y : crt_shard_tiles(st->nx, st->ny, rank, world);
     a.cooperative = pick_cooperative(ctx, a); // before the check: the cooperative kernel needs more record slack
-    if (wants_pieces(ctx, a) && reserve_pieces(ctx, a)) return CRT_OK; // crt_render takes the launch in two pieces
+    if (wants_pieces(ctx, a) && !(ctx->piece_overflowed && same_launch(a, ctx->piece_overflow_key)) && reserve_pieces(ctx, a))
+        return CRT_OK; // crt_render takes the launch in two pieces
     if (!crt::wavefront_supports(a)) return CRT_OK; // crt_render takes the persistent kernel (or refuses, if told to use the pipeline)
     const hipError_t reserved = reserve_workspace(ctx, a);
     if (reserved != hipSuccess) {

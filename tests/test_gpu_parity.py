@@ -455,6 +455,11 @@ def test_wavefront_redoes_a_round_when_the_ray_queue_overflows(oracle, monkeypat
         ref, _, ref_state = oracle.render(scene(oracle), st, 3, want_state=True)
         assert np.array_equal(state, ref_state)
         assert np.array_equal(fb, ref)
+        # the next frame of the same launch continues from there (in pieces mode it no longer tries the pieces)
+        fb2 = ctx.render_to_host(st)
+        ref2, _, ref_state2 = oracle.render(scene(oracle), st, 3, rng_state=ref_state, want_state=True)
+        assert np.array_equal(fb2, ref2)
+        assert np.array_equal(ctx.rng_export(st.nx, st.ny), ref_state2)
     finally:
         ctx.close()
 
